@@ -1,0 +1,104 @@
+#!/usr/bin/env python
+"""Generate golden vectors by importing the reference in the BUILD container.
+
+Run from the repo root:  ``python tests/golden/make_golden.py [group ...]``.
+It needs ``/root/reference`` (absent on the GPU box, where only the committed
+``.npz`` files are used).  Modules the reference imports but never uses on this
+path (torchvision, coloredlogs) are replaced by inert stubs, as SURVEY.md
+Appendix B documents.  Nothing is written outside ``tests/golden/``.
+
+Weights are never stored: every network is built under ``torch.manual_seed``
+and the fixture keeps a per-tensor digest of the reference's ``state_dict`` so
+the tests can prove the oracle's seeded re-initialisation is identical.
+"""
+import os
+import sys
+import types
+
+os.environ["MPLBACKEND"] = "Agg"
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+
+def _stub(name, subs=()):
+    m = types.ModuleType(name)
+    m.__path__ = []
+    sys.modules[name] = m
+    for s in subs:
+        sm = types.ModuleType(f"{name}.{s}")
+        setattr(m, s, sm)
+        sys.modules[f"{name}.{s}"] = sm
+    return m
+
+
+tv = _stub("torchvision", ("models", "datasets", "transforms", "utils"))
+tv.utils.save_image = lambda *a, **k: None
+_stub("coloredlogs").install = lambda *a, **k: None
+sys.path.insert(0, "/root/reference")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def digest(sd):
+    keys = sorted(sd.keys())
+    return (np.array(keys), np.array([[float(sd[k].double().sum()), float(sd[k].double().abs().sum())] for k in keys]))
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrs)
+    print(f"wrote {path}  {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+# --------------------------------------------------------------------------- lineage B
+def gen_lineage_b():
+    import diff_model as dm
+    dm.tqdm = lambda it, **k: it
+
+    # schedules and step sequences (diff_model.py:269-331, 428-440)
+    out = {}
+    for sched in ("cosine", "linear"):
+        gd = dm.GaussianDiffusion(beta_schedule=sched)
+        out[f"ac_{sched}"] = gd.alphas_cumprod.numpy()
+    save("lineage_b_schedules.npz", **out)
+
+    def run(tag, seed, hp, S, B, ts, steps):
+        torch.manual_seed(seed)
+        net = dm.UNetModel(**hp).eval()
+        keys, dg = digest(net.state_dict())
+        g = torch.Generator().manual_seed(1000 + seed)
+        x = torch.randn(B, 3, S, S, generator=g)
+        arrs = dict(sd_keys=keys, sd_digest=dg, x=x.numpy(), ts=np.array(ts))
+        with torch.no_grad():
+            for t in ts:
+                arrs[f"eps_t{t}"] = net(x, torch.full((B,), t, dtype=torch.long)).numpy()
+        for sched in ("cosine", "linear"):
+            gd = dm.GaussianDiffusion(beta_schedule=sched)
+            torch.manual_seed(1234)
+            xT = torch.randn((B, 3, S, S))          # what ddim_sample draws first (diff_model.py:444)
+            torch.manual_seed(1234)
+            res = gd.ddim_sample(net, S, batch_size=B, channels=3, ddim_timesteps=steps)
+            arrs[f"ddim_xT_{sched}"] = xT.numpy()
+            arrs[f"ddim_out_{sched}"] = res
+        arrs["ddim_steps"] = np.array(steps)
+        save(f"lineage_b_{tag}.npz", **arrs)
+
+    small = dict(model_channels=64, channel_mult=(1, 2), num_res_blocks=1, attention_resolutions=(2,), num_heads=4)
+    run("small", 3, small, 32, 2, [1, 501, 981], 5)
+    # attention at two levels + three res blocks + no-attention level, odd head count
+    mid = dict(model_channels=64, channel_mult=(1, 2, 3), num_res_blocks=2, attention_resolutions=(1, 4), num_heads=2)
+    run("mid", 5, mid, 32, 1, [21, 741], 4)
+    # BASELINE config 0: UNetModel() defaults, 1x3x64x64, 10-step DDIM
+    run("default", 0, {}, 64, 1, [1, 501, 981], 10)
+
+
+GROUPS = {"lineage_b": gen_lineage_b}
+
+if __name__ == "__main__":
+    for g in (sys.argv[1:] or list(GROUPS)):
+        GROUPS[g]()

@@ -1,0 +1,66 @@
+"""The CPU oracle vs golden vectors produced by the imported reference (diff_model.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import lineage_b as ob
+
+CASES = {
+    "small": (3, dict(model_channels=64, channel_mult=(1, 2), num_res_blocks=1, attention_resolutions=(2,), num_heads=4)),
+    "mid": (5, dict(model_channels=64, channel_mult=(1, 2, 3), num_res_blocks=2, attention_resolutions=(1, 4), num_heads=2)),
+    "default": (0, {}),
+}
+TOL = 2e-5   # fp32 run-to-run noise of the reference itself is 7.6e-6
+
+
+def test_schedules(golden):
+    g = golden("lineage_b_schedules.npz")
+    for sched in ("cosine", "linear"):
+        ac = ob.alphas_cumprod(1000, sched).numpy()
+        assert np.array_equal(ac, g[f"ac_{sched}"])        # float64, bit-exact
+
+
+def test_step_sequences():
+    # SURVEY §8 a10 [probed]: 10 -> [1,101,..,901]; 50 -> [1,21,..,981]; 100 -> [1,11,..,991]
+    for steps, c in ((10, 100), (50, 20), (100, 10)):
+        seq, prev = ob.ddim_sequences(1000, steps)
+        assert list(seq) == [1 + c * i for i in range(steps)]
+        assert list(prev) == [0] + list(seq[:-1])
+
+
+@pytest.mark.parametrize("tag", list(CASES))
+def test_seeded_init_matches_reference(golden, tag):
+    seed, over = CASES[tag]
+    g = golden(f"lineage_b_{tag}.npz")
+    sd = ob.init_state_dict(seed, ob.hparams(**over))
+    keys = list(g["sd_keys"])
+    assert sorted(sd.keys()) == keys
+    dg = ob.state_dict_digest(sd)
+    mine = np.array([dg[k] for k in keys])
+    assert np.array_equal(mine, g["sd_digest"])
+
+
+@pytest.mark.parametrize("tag", list(CASES))
+def test_forward_matches_reference(golden, tag):
+    seed, over = CASES[tag]
+    g = golden(f"lineage_b_{tag}.npz")
+    hp = ob.hparams(**over)
+    sd = ob.init_state_dict(seed, hp)
+    x = torch.from_numpy(g["x"])
+    for t in g["ts"]:
+        eps = ob.unet_forward(sd, hp, x, torch.full((x.shape[0],), int(t), dtype=torch.long)).numpy()
+        assert np.abs(eps - g[f"eps_t{t}"]).max() < TOL
+
+
+@pytest.mark.parametrize("tag", list(CASES))
+@pytest.mark.parametrize("sched", ["cosine", "linear"])
+def test_ddim_loop_matches_reference(golden, tag, sched):
+    seed, over = CASES[tag]
+    g = golden(f"lineage_b_{tag}.npz")
+    hp = ob.hparams(**over)
+    sd = ob.init_state_dict(seed, hp)
+    xT = torch.from_numpy(g[f"ddim_xT_{sched}"])
+    out = ob.ddim_sample(lambda x, t: ob.unet_forward(sd, hp, x, t), xT, schedule=sched, steps=int(g["ddim_steps"]))
+    ref = g[f"ddim_out_{sched}"]
+    assert out.dtype == np.float32 and out.shape == ref.shape
+    assert np.abs(out - ref).max() < 1e-4
