@@ -1,0 +1,104 @@
+"""ctypes binding of ``libadvshadow_hip.so`` (the C ABI declared in ``include/advshadow.h``).
+
+There is no CPU fallback: if the shared library has not been built (``__graft_entry__.build()``
+or ``make -C csrc``) importing a kernel raises, and every call checks its status code.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libadvshadow_hip.so")
+
+F32, BF16 = 0, 1
+ACT = {"none": 0, None: 0, "relu": 1, "silu": 2, "gelu": 3, "relu6": 4, "lrelu": 5, "lrelu001": 6}
+
+vp, i32, f32, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+
+class ConvArgs(C.Structure):
+    """Mirror of ``advs_conv_args``."""
+    _fields_ = [("x1", vp), ("x2", vp), ("w", vp), ("bias", vp), ("temb", vp), ("residual", vp), ("y", vp),
+                ("b", i32), ("h", i32), ("w_", i32), ("c1", i32), ("c2", i32), ("cout", i32),
+                ("ksize", i32), ("stride", i32), ("pad", i32), ("upsample", i32),
+                ("act", i32), ("dtype", i32), ("temb_stride", i32)]
+
+
+# name -> argtypes (restype is int unless listed in _RESTYPES)
+SIGNATURES = {
+    "advs_init": [],
+    "advs_abi_version": [],
+    "advs_pack_conv_weight": [vp, vp, i32, i32, i32, i32, i32, vp],
+    "advs_nchw_f32_to_nhwc": [vp, vp, i32, i32, i32, i32, i32, vp],
+    "advs_nhwc_to_nchw_f32": [vp, vp, i32, i32, i32, i32, i32, vp],
+    "advs_conv2d": [C.POINTER(ConvArgs), vp],
+    "advs_conv3x3_first": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "advs_conv_last": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    "advs_groupnorm": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    "advs_attention": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "advs_linear_f32": [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "advs_timestep_embedding": [vp, vp, i32, i32, vp, vp, vp, i32, vp],
+    "advs_ddim_step": [vp, vp, vp, f32, vp, vp, vp, i32, vp, vp, i32, sz, i32, vp],
+    "advs_to_uint8": [vp, vp, sz, i32, vp],
+    "advs_graph_begin": [vp],
+    "advs_graph_end": [vp, C.POINTER(vp)],
+    "advs_graph_launch": [vp, vp],
+    "advs_graph_destroy": [vp],
+    "advs_event_create": [C.POINTER(vp)],
+    "advs_event_record": [vp, vp],
+    "advs_event_elapsed_ms": [vp, vp, C.POINTER(f32)],
+    "advs_event_destroy": [vp],
+    "advs_stream_sync": [vp],
+}
+_RESTYPES = {"advs_last_error": C.c_char_p, "advs_groupnorm_scratch_bytes": sz}
+_EXTRA = {"advs_last_error": [], "advs_groupnorm_scratch_bytes": [i32, i32]}
+
+_lib = None
+
+
+class AdvsError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise AdvsError(f"{LIB_PATH} is missing: build it with __graft_entry__.build() "
+                            f"(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        lib = C.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.argtypes = args
+            fn.restype = C.c_int
+        for name, args in _EXTRA.items():
+            fn = getattr(lib, name)
+            fn.argtypes = args
+            fn.restype = _RESTYPES[name]
+        _lib = lib
+    return _lib
+
+
+def exported_symbols():
+    """Every entry point ``include/advshadow.h`` declares (used by the CPU-side ABI test)."""
+    return list(SIGNATURES) + list(_EXTRA)
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().advs_last_error()
+        raise AdvsError(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")
+
+
+_initialised = set()
+
+
+def init_device():
+    """Allocate the library's zero page on the current device (idempotent)."""
+    import torch
+    if not torch.cuda.is_available():
+        raise AdvsError("no GPU visible: the AdvShadow HIP path needs an MI355X (there is no CPU fallback)")
+    dev = torch.cuda.current_device()
+    if dev not in _initialised:
+        check(load().advs_init(), "advs_init")
+        _initialised.add(dev)

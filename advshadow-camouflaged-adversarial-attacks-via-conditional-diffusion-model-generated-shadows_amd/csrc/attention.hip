@@ -1,0 +1,224 @@
+// Flash-style self-attention on the matrix cores: softmax(q k^T / sqrt(d)) v per (batch, head)
+// with an online softmax, never materialising the N x N scores.
+//
+// Workgroup = 4 waves = 128 queries of one (batch, head); each wave owns 32 queries and walks
+// the keys in tiles of 64.  Scores are computed TRANSPOSED, S^T = K Q^T, so that in the 32x32
+// accumulator layout the query sits on the lane and the keys on the registers: the row max /
+// row sum are in-register reductions plus one exchange with lane^32, and the exponentiated
+// tile is, register for register, the B operand of the next product O^T += V^T P^T (no LDS
+// round trip).  V is transposed once while staging it into LDS.
+//
+// FLOPs per launch: 4 * B * heads * N^2 * d.
+#include "common.h"
+
+#define AT_THREADS 256
+#define KT 64          // keys per tile
+
+struct AttnP {
+    const char* qkv; char* out;
+    int B, N, heads, d, ld, q_off, k_off, v_off, head_stride;
+    float scale_log2e;
+};
+
+template <typename T> struct AMma;
+template <> struct AMma<BF16> { static constexpr int ESZ = 2; };
+template <> struct AMma<float> { static constexpr int ESZ = 4; };
+
+template <typename T, int DT>
+__global__ void __launch_bounds__(AT_THREADS)
+attn_kernel(const AttnP p) {
+    constexpr int ESZ = AMma<T>::ESZ;
+    constexpr int VEC = 16 / ESZ;
+    constexpr int DMAX = DT * 32;
+    constexpr int KS = DMAX * ESZ + 16;           // K tile row stride (bytes), padded
+    constexpr int VS = KT * ESZ + 16;             // V^T tile row stride (bytes), padded
+    constexpr int QSTEPS = DMAX * ESZ / 32;       // max 32-byte k-steps over d
+    extern __shared__ __attribute__((aligned(16))) char sm[];     // KT*KS + DMAX*VS bytes
+    char* sK = sm;
+    char* sV = sm + KT * KS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int b = blockIdx.z, hd = blockIdx.y;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const bool active = q0 < p.N;
+    const int d = p.d;
+    const int dsteps = d * ESZ / 32;              // 32-byte steps actually used
+    const size_t rowb = (size_t)p.ld * ESZ;
+    const char* base = p.qkv + (size_t)b * p.N * rowb;
+    const char* qp = base + (size_t)(p.q_off + hd * p.head_stride) * ESZ;
+    const char* kp = base + (size_t)(p.k_off + hd * p.head_stride) * ESZ;
+    const char* vp = base + (size_t)(p.v_off + hd * p.head_stride) * ESZ;
+
+    // Q fragments: lane (query l31, half lh) holds bytes [32*s + 16*lh, +16) of its query row
+    u32x4 qf[QSTEPS];
+#pragma unroll
+    for (int s = 0; s < QSTEPS; ++s) {
+        if (active && s < dsteps) qf[s] = *(const u32x4*)(qp + (size_t)(q0 + l31) * rowb + s * 32 + lh * 16);
+        else qf[s] = u32x4{0, 0, 0, 0};
+    }
+
+    f32x16 o[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int cpr = d * ESZ / 16;                 // 16-byte chunks per K/V row
+    const int nvec = KT * cpr;
+
+    for (int k0 = 0; k0 < p.N; k0 += KT) {
+        __syncthreads();                          // previous tile fully consumed
+        for (int v = tid; v < nvec; v += AT_THREADS) {
+            const int key = v / cpr, ch = v - key * cpr;
+            const size_t g = (size_t)(k0 + key) * rowb + ch * 16;
+            const u32x4 kv = *(const u32x4*)(kp + g);
+            const u32x4 vv = *(const u32x4*)(vp + g);
+            *(u32x4*)(sK + key * KS + ch * 16) = kv;
+            if (ESZ == 2) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    unsigned short h = (unsigned short)((vv[e >> 1] >> ((e & 1) * 16)) & 0xffff);
+                    *(unsigned short*)(sV + (ch * 8 + e) * VS + key * 2) = h;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) *(unsigned*)(sV + (ch * 4 + e) * VS + key * 4) = vv[e];
+            }
+        }
+        __syncthreads();
+        if (!active) continue;
+
+        // ---- S^T = K Q^T for the two 32-key blocks
+        f32x16 st[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < QSTEPS; ++s) {
+                if (s < dsteps) {
+                    const u32x4 kf = *(const u32x4*)(sK + (kb * 32 + l31) * KS + s * 32 + lh * 16);
+                    if (ESZ == 2) {
+                        st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf),
+                                                                        __builtin_bit_cast(bf16x8, qf[s]), st[kb], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            st[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(kf[j]), __uint_as_float(qf[s][j]),
+                                                                          st[kb], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // ---- online softmax over this tile's 64 keys (32 in this lane, 32 in lane^32)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { st[kb][r] *= p.scale_log2e; mx = fmaxf(mx, st[kb][r]); }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = exp2f(m_run - m_new);          // exp2(-inf) = 0 on the first tile
+        float ls = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { st[kb][r] = exp2f(st[kb][r] - m_new); ls += st[kb][r]; }
+        l_run = l_run * alpha + ls;
+        m_run = m_new;
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+
+        // ---- O^T += V^T P^T ; P^T registers are the B operand as they stand
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            if (ESZ == 2) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    u32x4 pf;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w)
+                        pf[w] = (unsigned)f32_to_bf16(st[kb][8 * s2 + 2 * w]) |
+                                ((unsigned)f32_to_bf16(st[kb][8 * s2 + 2 * w + 1]) << 16);
+#pragma unroll
+                    for (int t = 0; t < DT; ++t) {
+                        const char* vr = sV + (t * 32 + l31) * VS + (kb * 32 + 16 * s2 + 4 * lh) * 2;
+                        const u32x2 lo = *(const u32x2*)vr;            // keys +0..3
+                        const u32x2 hi = *(const u32x2*)(vr + 16);     // keys +8..11
+                        const u32x4 vf = u32x4{lo[0], lo[1], hi[0], hi[1]};
+                        o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf),
+                                                                      __builtin_bit_cast(bf16x8, pf), o[t], 0, 0, 0);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                    for (int t = 0; t < DT; ++t) {
+                        const u32x4 vf = *(const u32x4*)(sV + (t * 32 + l31) * VS + (kb * 32 + 8 * g + 4 * lh) * 4);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(vf[j]), st[kb][4 * g + j], o[t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    if (!active) return;
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    T* orow = (T*)p.out + ((size_t)b * p.N + q0 + l31) * (size_t)(p.heads * d) + hd * d;
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int di = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (di < d) Elt<T>::st(orow + di, o[t][r] * inv);
+        }
+}
+
+template <typename T, int DT>
+static int attn_launch_dt(const AttnP& p, hipStream_t st) {
+    constexpr int ESZ = AMma<T>::ESZ;
+    constexpr size_t lds = (size_t)KT * (DT * 32 * ESZ + 16) + (size_t)DT * 32 * (KT * ESZ + 16);
+    static bool attr_set = false;                 // opt in once per instantiation (> 64 KiB for f32, d = 128)
+    if (!attr_set) {
+        ADVS_HIP(hipFuncSetAttribute((const void*)attn_kernel<T, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    dim3 grid(cdiv(p.N, 128), p.heads, p.B);
+    attn_kernel<T, DT><<<grid, AT_THREADS, lds, st>>>(p);
+    ADVS_CHECK_LAUNCH("attention");
+    return ADVS_OK;
+}
+
+template <typename T>
+static int attn_launch(const AttnP& p, hipStream_t st) {
+    switch ((p.d + 31) / 32) {
+        case 1: return attn_launch_dt<T, 1>(p, st);
+        case 2: return attn_launch_dt<T, 2>(p, st);
+        case 3: return attn_launch_dt<T, 3>(p, st);
+        default: return attn_launch_dt<T, 4>(p, st);
+    }
+}
+
+extern "C" int advs_attention(const void* qkv, void* out, int b, int n, int heads, int d, int ld,
+                              int q_off, int k_off, int v_off, int head_stride, int dtype, void* stream) {
+    ADVS_REQUIRE(qkv && out && b > 0 && n > 0 && heads > 0 && d > 0, "attention: bad args");
+    ADVS_REQUIRE(n % KT == 0, "attention: n=%d must be a multiple of %d", n, KT);
+    ADVS_REQUIRE(d % 16 == 0 && d <= 128, "attention: d=%d must be a multiple of 16 and <= 128", d);
+    const int vec = dtype == ADVS_BF16 ? 8 : 4;
+    ADVS_REQUIRE(ld % vec == 0 && q_off % vec == 0 && k_off % vec == 0 && v_off % vec == 0 && head_stride % vec == 0,
+                 "attention: offsets must keep 16-byte alignment");
+    AttnP p;
+    p.qkv = (const char*)qkv; p.out = (char*)out;
+    p.B = b; p.N = n; p.heads = heads; p.d = d; p.ld = ld;
+    p.q_off = q_off; p.k_off = k_off; p.v_off = v_off; p.head_stride = head_stride;
+    p.scale_log2e = (float)(1.4426950408889634 / sqrt((double)d));
+    if (dtype == ADVS_BF16) return attn_launch<BF16>(p, (hipStream_t)stream);
+    return attn_launch<float>(p, (hipStream_t)stream);
+}

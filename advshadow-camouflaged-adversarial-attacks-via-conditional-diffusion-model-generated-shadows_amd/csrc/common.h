@@ -1,0 +1,93 @@
+// Shared helpers for the gfx950 kernels behind the C-ABI in include/advshadow.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/advshadow.h"
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) short bf16x8;   // 8 bf16 = one MFMA A/B fragment
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+// ---- error plumbing -------------------------------------------------------
+void advs_set_error(const char* fmt, ...);
+#define ADVS_FAIL(code, ...) do { advs_set_error(__VA_ARGS__); return (code); } while (0)
+#define ADVS_REQUIRE(cond, ...) do { if (!(cond)) ADVS_FAIL(ADVS_ERR_ARG, __VA_ARGS__); } while (0)
+#define ADVS_CHECK_LAUNCH(name) do { hipError_t e__ = hipGetLastError(); \
+    if (e__ != hipSuccess) ADVS_FAIL(ADVS_ERR_HIP, "%s: %s", name, hipGetErrorString(e__)); } while (0)
+#define ADVS_HIP(call) do { hipError_t e__ = (call); \
+    if (e__ != hipSuccess) ADVS_FAIL(ADVS_ERR_HIP, "%s: %s", #call, hipGetErrorString(e__)); } while (0)
+
+// ---- element types ----------------------------------------------------------
+// Activations and GEMM weights are either f32 (parity mode, exact-f32 MFMA) or bf16
+// (throughput mode, bf16 MFMA with f32 accumulation).  Storage type of bf16 is a raw u16.
+struct BF16 { unsigned short v; };
+
+__device__ __forceinline__ float bf16_to_f32(unsigned short u) { return __uint_as_float(((unsigned)u) << 16); }
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+    __bf16 b = (__bf16)f;                       // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+    return __builtin_bit_cast(unsigned short, b);
+}
+
+template <typename T> struct Elt;
+template <> struct Elt<float> {
+    static constexpr int VEC = 4;               // elements per 16 bytes
+    __device__ static __forceinline__ float ld(const float* p) { return *p; }
+    __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Elt<BF16> {
+    static constexpr int VEC = 8;
+    __device__ static __forceinline__ float ld(const BF16* p) { return bf16_to_f32(p->v); }
+    __device__ static __forceinline__ void st(BF16* p, float v) { p->v = f32_to_bf16(v); }
+};
+
+// 16-byte vector <-> floats
+template <typename T> __device__ __forceinline__ void unpack16(const u32x4& raw, float* out);
+template <> __device__ __forceinline__ void unpack16<float>(const u32x4& raw, float* out) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[i] = __uint_as_float(raw[i]);
+}
+template <> __device__ __forceinline__ void unpack16<BF16>(const u32x4& raw, float* out) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        out[2 * i] = __uint_as_float(raw[i] << 16);
+        out[2 * i + 1] = __uint_as_float(raw[i] & 0xffff0000u);
+    }
+}
+template <typename T> __device__ __forceinline__ u32x4 pack16(const float* in);
+template <> __device__ __forceinline__ u32x4 pack16<float>(const float* in) {
+    u32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = __float_as_uint(in[i]);
+    return r;
+}
+template <> __device__ __forceinline__ u32x4 pack16<BF16>(const float* in) {
+    u32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        r[i] = (unsigned)f32_to_bf16(in[2 * i]) | ((unsigned)f32_to_bf16(in[2 * i + 1]) << 16);
+    return r;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    switch (act) {
+        case ADVS_ACT_RELU: return v > 0.f ? v : 0.f;
+        case ADVS_ACT_SILU: return v / (1.0f + expf(-v));
+        case ADVS_ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+        case ADVS_ACT_RELU6: return fminf(fmaxf(v, 0.f), 6.f);
+        case ADVS_ACT_LRELU01: return v > 0.f ? v : 0.1f * v;
+        case ADVS_ACT_LRELU001: return v > 0.f ? v : 0.01f * v;
+        default: return v;
+    }
+}
+
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+static inline size_t dtype_size(int dt) { return dt == ADVS_BF16 ? 2 : 4; }
+
+// 128 zero bytes every lane may read instead of an out-of-image / out-of-range row.
+const void* advs_zero_page();

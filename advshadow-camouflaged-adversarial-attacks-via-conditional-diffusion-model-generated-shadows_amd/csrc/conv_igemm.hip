@@ -1,0 +1,239 @@
+// Conv2d as an implicit GEMM on the CDNA4 matrix cores.
+//
+//   y[m][n] = act( sum_k A[m][k] * Wp[n][k] + bias[n] + temb[b(m)][n] + residual[m][n] )
+//   m = (b, oy, ox) output pixel, n = output channel, k = (r, s, c) filter tap x input channel.
+//
+// A is never materialised: every 128-byte K-slab of an A row is one contiguous NHWC channel
+// run of one source pixel (or the zero page outside the image), fetched straight into LDS by
+// global_load_lds (16 B per lane, per-lane source address = the im2col gather).  The gather
+// also performs the channel concat of two sources and the nearest x2 upsample.
+//
+// Tile: 128(M) x 128(N) x 128 B of K per step; 4 waves, each a 64x64 block of 2x2 MFMA
+// 32x32 tiles.  bf16: v_mfma_f32_32x32x16_bf16; f32: v_mfma_f32_32x32x2_f32 (exact f32).
+// LDS: double-buffered A and B tiles (64 KiB), rows of 128 B with the 16-byte chunk index
+// XOR-ed by (row>>1)&7 so every ds_read_b128 of a fragment is bank-conflict free; since the
+// DMA writes LDS linearly the same XOR is applied to the per-lane SOURCE address.
+//
+// Roofline: MFMA-bound.  Algorithmic FLOPs per launch = 2*M*N*K.
+#include "common.h"
+
+#define BM 128
+#define BN 128
+#define SLAB 128                 // bytes of K per row per step
+#define TILE_BYTES (BM * SLAB)   // 16 KiB per operand tile
+#define NTHREADS 256
+
+struct ConvKP {
+    const char* x1; const char* x2; const char* w;
+    const float* bias; const float* temb; const char* res; char* y;
+    const char* zero;
+    int B, H, W, C1, C2, Cout;
+    int R, stride, pad, ups;
+    int Ho, Wo, M, K;            // K in elements
+    int act, temb_stride;
+    int nMt, nNt;
+};
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+__device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)lds_wave_base, 16, 0, 0);
+}
+
+template <typename T> struct Mma;
+template <> struct Mma<BF16> {
+    static constexpr int ESZ = 2;
+    // one 16-byte fragment per operand = K of 16 (two lane halves x 8)
+    __device__ static __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    static constexpr int ESZ = 4;
+    // 16 bytes = 4 floats per lane half; float j of both halves forms one K=2 step
+    __device__ static __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[j]), __uint_as_float(b[j]), c, 0, 0, 0);
+    }
+};
+
+template <typename T>
+__global__ void __launch_bounds__(NTHREADS)
+conv_igemm_kernel(const ConvKP p) {
+    constexpr int ESZ = Mma<T>::ESZ;
+    constexpr int BKE = SLAB / ESZ;                       // K elements per slab
+    __shared__ __attribute__((aligned(1024))) char smem[4 * TILE_BYTES];   // A0 B0 A1 B1
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- XCD-aware tile order: blocks that share an XCD (id % 8) walk neighbouring tiles,
+    // N tiles of one M tile first, so the A rows are re-read from that XCD's L2.
+    const int nblk = p.nMt * p.nNt;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int mt = bid / p.nNt, nt = bid - mt * p.nNt;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    // ---- per-lane staging geometry: 4 A rows and 4 B rows per lane, one 16-B chunk each
+    const int HoWo = p.Ho * p.Wo;
+    const int Cin = p.C1 + p.C2;
+    const int HL = p.H << p.ups, WL = p.W << p.ups;
+    const int chunk = lane & 7;
+    int a_b[4], a_iy[4], a_ix[4];
+    int csw[4];                                          // swizzled chunk byte offset
+    const char* b_src[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = (wave * 4 + j) * 8 + (lane >> 3);
+        csw[j] = ((chunk ^ ((row >> 1) & 7)) << 4);
+        const int m = m0 + row;
+        if (m < p.M) {
+            const int b = m / HoWo, rem = m - b * HoWo;
+            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            a_b[j] = b; a_iy[j] = oy * p.stride - p.pad; a_ix[j] = ox * p.stride - p.pad;
+        } else {
+            a_b[j] = 0; a_iy[j] = -0x40000000; a_ix[j] = 0;      // always out of the image
+        }
+        const int n = n0 + row;
+        b_src[j] = (n < p.Cout) ? p.w + ((size_t)n * p.K) * ESZ + csw[j] : nullptr;
+    }
+
+    // K-slab cursor (uniform): tap (r, s) and channel offset c0 inside the concatenated input
+    int kr = 0, ks = 0, c0 = 0;
+    const int nk = p.K / BKE;
+
+    auto stage = [&](int buf, int kt) {
+        char* la = smem + buf * 2 * TILE_BYTES;
+        char* lb = la + TILE_BYTES;
+        const bool first = c0 < p.C1;
+        const char* src = first ? p.x1 : p.x2;
+        const int cs = first ? p.C1 : p.C2;
+        const int cc = first ? c0 : c0 - p.C1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int iy = a_iy[j] + kr, ix = a_ix[j] + ks;
+            const bool ok = (unsigned)iy < (unsigned)HL && (unsigned)ix < (unsigned)WL;
+            const size_t pix = ((size_t)a_b[j] * p.H + (iy >> p.ups)) * p.W + (ix >> p.ups);
+            const char* s = ok ? src + (pix * cs + cc) * ESZ + csw[j] : p.zero + csw[j];
+            glds16(s, la + (wave * 4 + j) * 1024);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const char* s = b_src[j] ? b_src[j] + (size_t)kt * SLAB : p.zero + csw[j];
+            glds16(s, lb + (wave * 4 + j) * 1024);
+        }
+        c0 += BKE;
+        if (c0 == Cin) { c0 = 0; if (++ks == p.R) { ks = 0; ++kr; } }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+    // fragment read offsets (bytes inside a tile) for k-step s: row*128 + ((2s+lh) ^ sw(row))*16
+    int a_off[2], b_off[2], a_sw[2], b_sw[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ra = wr * 64 + i * 32 + l31, rb = wc * 64 + i * 32 + l31;
+        a_off[i] = ra * SLAB; a_sw[i] = (ra >> 1) & 7;
+        b_off[i] = rb * SLAB; b_sw[i] = (rb >> 1) & 7;
+    }
+
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) {
+            stage(buf ^ 1, kt + 1);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // slab kt landed, kt+1 in flight
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        const char* la = smem + buf * 2 * TILE_BYTES;
+        const char* lb = la + TILE_BYTES;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            u32x4 af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[i] = *(const u32x4*)(la + a_off[i] + ((((2 * s + lh) ^ a_sw[i])) << 4));
+                bf[i] = *(const u32x4*)(lb + b_off[i] + ((((2 * s + lh) ^ b_sw[i])) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) Mma<T>::run(af[i], bf[j], acc[i][j]);
+        }
+        __builtin_amdgcn_s_barrier();                            // all reads of buf done before restage
+    }
+
+    // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    T* y = (T*)p.y;
+    const T* res = (const T*)p.res;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wc * 64 + j * 32 + l31;
+        if (n >= p.Cout) continue;
+        const float bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= p.M) continue;
+                float v = acc[i][j][r] + bias;
+                if (p.temb) v += p.temb[(size_t)(m / HoWo) * p.temb_stride + n];
+                const size_t o = (size_t)m * p.Cout + n;
+                if (res) v += Elt<T>::ld(res + o);
+                Elt<T>::st(y + o, apply_act(v, p.act));
+            }
+        }
+    }
+}
+
+extern "C" int advs_conv2d(const advs_conv_args* a, void* stream) {
+    ADVS_REQUIRE(a && a->x1 && a->w && a->y, "conv2d: null pointer");
+    ADVS_REQUIRE(a->b > 0 && a->h > 0 && a->w_ > 0 && a->c1 > 0 && a->c2 >= 0 && a->cout > 0, "conv2d: bad shape");
+    ADVS_REQUIRE(a->ksize == 1 || a->ksize == 3, "conv2d: ksize %d unsupported", a->ksize);
+    ADVS_REQUIRE(a->stride == 1 || a->stride == 2, "conv2d: stride %d unsupported", a->stride);
+    ADVS_REQUIRE(a->pad >= 0 && a->pad <= 1, "conv2d: pad %d unsupported", a->pad);
+    ADVS_REQUIRE((a->c2 == 0) == (a->x2 == nullptr), "conv2d: x2/c2 mismatch");
+    const int esz = a->dtype == ADVS_BF16 ? 2 : 4;
+    const int bke = SLAB / esz;
+    ADVS_REQUIRE(a->c1 % bke == 0 && a->c2 % bke == 0, "conv2d: channels (%d,%d) must be multiples of %d",
+                 a->c1, a->c2, bke);
+    const void* zero = advs_zero_page();
+    ADVS_REQUIRE(zero, "conv2d: advs_init() has not been called on this device");
+    ConvKP p;
+    p.x1 = (const char*)a->x1; p.x2 = (const char*)a->x2; p.w = (const char*)a->w;
+    p.bias = a->bias; p.temb = a->temb; p.res = (const char*)a->residual; p.y = (char*)a->y;
+    p.zero = (const char*)zero;
+    p.B = a->b; p.H = a->h; p.W = a->w_; p.C1 = a->c1; p.C2 = a->c2; p.Cout = a->cout;
+    p.R = a->ksize; p.stride = a->stride; p.pad = a->pad; p.ups = a->upsample ? 1 : 0;
+    const int HL = a->h << p.ups, WL = a->w_ << p.ups;
+    p.Ho = (HL + 2 * a->pad - a->ksize) / a->stride + 1;
+    p.Wo = (WL + 2 * a->pad - a->ksize) / a->stride + 1;
+    const long long M = (long long)a->b * p.Ho * p.Wo;
+    ADVS_REQUIRE(M > 0 && M < (1ll << 31) - BM, "conv2d: M=%lld out of range", M);
+    p.M = (int)M;
+    p.K = a->ksize * a->ksize * (a->c1 + a->c2);
+    p.act = a->act; p.temb_stride = a->temb_stride > 0 ? a->temb_stride : a->cout;
+    p.nMt = cdiv(M, BM); p.nNt = cdiv(a->cout, BN);
+    const int grid = p.nMt * p.nNt;
+    if (a->dtype == ADVS_BF16) conv_igemm_kernel<BF16><<<grid, NTHREADS, 0, (hipStream_t)stream>>>(p);
+    else conv_igemm_kernel<float><<<grid, NTHREADS, 0, (hipStream_t)stream>>>(p);
+    ADVS_CHECK_LAUNCH("conv_igemm");
+    return ADVS_OK;
+}

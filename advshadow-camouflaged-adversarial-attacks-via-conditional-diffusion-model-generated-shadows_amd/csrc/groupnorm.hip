@@ -1,0 +1,183 @@
+// GroupNorm (+ activation, + residual) on NHWC activations.  HBM-bound: the statistics pass
+// reads x once; the apply pass reads x (and the residual) once and writes y once.
+// Algorithmic traffic: 3 * B*HW*C*sizeof(T) bytes (4x with a residual).
+//
+// Determinism: statistics are reduced in a fixed order (per-thread f32 sums -> LDS tree ->
+// per-chunk partials -> f64 combine), no atomics, so a sample's result does not depend on
+// the batch it is in or on the GPU it runs on.
+#include "common.h"
+
+#define GN_MAX_CHUNKS 256
+#define GN_THREADS 256
+
+extern "C" size_t advs_groupnorm_scratch_bytes(int b, int groups) {
+    return (size_t)b * GN_MAX_CHUNKS * groups * 2 * sizeof(float);
+}
+
+// thread layout shared by both passes: tid -> (pixel lane pl, channel vector cv)
+template <typename T>
+__global__ void __launch_bounds__(GN_THREADS)
+gn_partial_kernel(const T* __restrict__ x, const T* __restrict__ x2, int C1, float* __restrict__ partials,
+                  int HW, int C, int G, int nchunk) {
+    constexpr int VEC = Elt<T>::VEC;
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // [PIXB][C][2]
+    const int vpp = C / VEC, PIXB = GN_THREADS / vpp;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int tid = threadIdx.x, pl = tid / vpp, cv = tid - pl * vpp;
+    const int per = (HW + nchunk - 1) / nchunk;
+    const int p0 = chunk * per, p1 = min(HW, p0 + per);
+    float s[VEC], q[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { s[j] = 0.f; q[j] = 0.f; }
+    if (pl < PIXB) {
+        // channel vector cv lives in source 1 (C1 channels) or source 2 (C - C1 channels)
+        const int v1 = C1 / VEC;
+        const bool in1 = cv < v1;
+        const int vs = in1 ? v1 : vpp - v1;                       // vectors per pixel in that source
+        const u32x4* base = in1 ? (const u32x4*)(x + (size_t)b * HW * C1) + cv
+                                : (const u32x4*)(x2 + (size_t)b * HW * (C - C1)) + (cv - v1);
+        int p = p0 + pl;
+        for (; p + 3 * PIXB < p1; p += 4 * PIXB) {                 // 4 loads in flight
+            u32x4 r0 = base[(size_t)p * vs], r1 = base[(size_t)(p + PIXB) * vs];
+            u32x4 r2 = base[(size_t)(p + 2 * PIXB) * vs], r3 = base[(size_t)(p + 3 * PIXB) * vs];
+            float f[VEC];
+            unpack16<T>(r0, f);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { s[j] += f[j]; q[j] = fmaf(f[j], f[j], q[j]); }
+            unpack16<T>(r1, f);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { s[j] += f[j]; q[j] = fmaf(f[j], f[j], q[j]); }
+            unpack16<T>(r2, f);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { s[j] += f[j]; q[j] = fmaf(f[j], f[j], q[j]); }
+            unpack16<T>(r3, f);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { s[j] += f[j]; q[j] = fmaf(f[j], f[j], q[j]); }
+        }
+        for (; p < p1; p += PIXB) {
+            u32x4 r0 = base[(size_t)p * vs];
+            float f[VEC];
+            unpack16<T>(r0, f);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { s[j] += f[j]; q[j] = fmaf(f[j], f[j], q[j]); }
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            sm[((size_t)pl * C + cv * VEC + j) * 2] = s[j];
+            sm[((size_t)pl * C + cv * VEC + j) * 2 + 1] = q[j];
+        }
+    }
+    __syncthreads();
+    // fold the pixel lanes: channel c -> sm[c][0..1] of lane 0
+    for (int c = tid; c < C; c += GN_THREADS) {
+        float a = sm[c * 2], d = sm[c * 2 + 1];
+        for (int l = 1; l < PIXB; ++l) { a += sm[((size_t)l * C + c) * 2]; d += sm[((size_t)l * C + c) * 2 + 1]; }
+        sm[c * 2] = a; sm[c * 2 + 1] = d;
+    }
+    __syncthreads();
+    // fold channels of a group: one wave per group, butterfly in a fixed order
+    const int cpg = C / G, wave = tid >> 6, lane = tid & 63;
+    for (int g = wave; g < G; g += GN_THREADS / 64) {
+        float a = 0.f, d = 0.f;
+        for (int c = lane; c < cpg; c += 64) { a += sm[(g * cpg + c) * 2]; d += sm[(g * cpg + c) * 2 + 1]; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); d += __shfl_xor(d, o); }
+        if (lane == 0) {
+            float* out = partials + (((size_t)b * nchunk + chunk) * G + g) * 2;
+            out[0] = a; out[1] = d;
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(GN_THREADS)
+gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ x2, int C1, const float* __restrict__ gamma,
+                const float* __restrict__ beta, const T* __restrict__ res, T* __restrict__ y,
+                const float* __restrict__ partials, int HW, int C, int G, int nchunk, int nblk, int act) {
+    constexpr int VEC = Elt<T>::VEC;
+    __shared__ float s_mean[64], s_rstd[64];
+    const int vpp = C / VEC, PIXB = GN_THREADS / vpp;
+    const int b = blockIdx.y, tid = threadIdx.x, cpg = C / G;
+    for (int g = tid; g < G; g += GN_THREADS) {
+        double a = 0.0, d = 0.0;
+        const float* p = partials + ((size_t)b * nchunk * G + g) * 2;
+        for (int k = 0; k < nchunk; ++k) { a += (double)p[(size_t)k * G * 2]; d += (double)p[(size_t)k * G * 2 + 1]; }
+        double n = (double)HW * cpg, mean = a / n, var = d / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        s_mean[g] = (float)mean;
+        s_rstd[g] = (float)(1.0 / sqrt(var + 1e-5));
+    }
+    __syncthreads();
+    const int pl = tid / vpp, cv = tid - pl * vpp;
+    if (pl >= PIXB) return;
+    float ca[VEC], cb[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        int c = cv * VEC + j, g = c / cpg;
+        float a = s_rstd[g] * gamma[c];
+        ca[j] = a;
+        cb[j] = beta[c] - s_mean[g] * a;
+    }
+    const int per = (HW + nblk - 1) / nblk;
+    const int p0 = blockIdx.x * per, p1 = min(HW, p0 + per);
+    const size_t sample = (size_t)b * HW * vpp;
+    const int v1 = C1 / VEC;
+    const bool in1 = cv < v1;
+    const int vs = in1 ? v1 : vpp - v1;
+    const u32x4* xb = in1 ? (const u32x4*)x + (size_t)b * HW * v1 + cv
+                          : (const u32x4*)x2 + (size_t)b * HW * (vpp - v1) + (cv - v1);
+    const u32x4* rb = res ? (const u32x4*)res + sample + cv : nullptr;
+    u32x4* yb = (u32x4*)y + sample + cv;
+    for (int p = p0 + pl; p < p1; p += PIXB) {
+        float f[VEC], r[VEC];
+        unpack16<T>(xb[(size_t)p * vs], f);
+        if (rb) unpack16<T>(rb[(size_t)p * vpp], r);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            float v = fmaf(f[j], ca[j], cb[j]);
+            if (rb) v += r[j];
+            f[j] = apply_act(v, act);
+        }
+        yb[(size_t)p * vpp] = pack16<T>(f);
+    }
+}
+
+template <typename T>
+static int gn_launch(const void* x, const void* x2, int c1, const float* gamma, const float* beta, const void* res,
+                     void* y, float* partials, int b, int hw, int c, int groups, int act, hipStream_t st) {
+    constexpr int VEC = Elt<T>::VEC;
+    const int vpp = c / VEC, PIXB = GN_THREADS / vpp;
+    // enough chunks to fill 256 CUs several times over, but >= 4 pixels per lane per chunk
+    int nchunk = 2048 / b;
+    int maxc = hw / (PIXB * 4);
+    if (nchunk > maxc) nchunk = maxc;
+    if (nchunk > GN_MAX_CHUNKS) nchunk = GN_MAX_CHUNKS;
+    if (nchunk < 1) nchunk = 1;
+    size_t lds = (size_t)PIXB * c * 2 * sizeof(float);
+    gn_partial_kernel<T><<<dim3(nchunk, b), GN_THREADS, lds, st>>>((const T*)x, (const T*)x2, c1, partials, hw, c, groups, nchunk);
+    ADVS_CHECK_LAUNCH("gn_partial");
+    int nblk = 4096 / b;
+    int maxb = hw / (PIXB * 2);
+    if (nblk > maxb) nblk = maxb;
+    if (nblk < 1) nblk = 1;
+    gn_apply_kernel<T><<<dim3(nblk, b), GN_THREADS, 0, st>>>((const T*)x, (const T*)x2, c1, gamma, beta, (const T*)res,
+                                                             (T*)y, partials, hw, c, groups, nchunk, nblk, act);
+    ADVS_CHECK_LAUNCH("gn_apply");
+    return ADVS_OK;
+}
+
+extern "C" int advs_groupnorm(const void* x, const void* x2, const float* gamma, const float* beta,
+                              const void* residual_in, void* y, void* partials, int b, int hw, int c1, int c2,
+                              int groups, int act, int dtype, void* stream) {
+    ADVS_REQUIRE(x && gamma && beta && y && partials, "groupnorm: null pointer");
+    ADVS_REQUIRE(c1 > 0 && c2 >= 0 && (c2 == 0) == (x2 == nullptr), "groupnorm: x2/c2 mismatch");
+    const int c = c1 + c2;
+    ADVS_REQUIRE(b > 0 && hw > 0 && c > 0 && groups > 0 && groups <= 64 && c % groups == 0,
+                 "groupnorm: bad shape b=%d hw=%d c=%d groups=%d", b, hw, c, groups);
+    const int vec = dtype == ADVS_BF16 ? 8 : 4;
+    ADVS_REQUIRE(c1 % vec == 0 && c2 % vec == 0 && c / vec <= GN_THREADS, "groupnorm: c=%d+%d unsupported for dtype %d", c1, c2, dtype);
+    ADVS_REQUIRE((size_t)(GN_THREADS / (c / vec)) * c * 8 <= 65536, "groupnorm: LDS budget exceeded for c=%d", c);
+    if (dtype == ADVS_BF16)
+        return gn_launch<BF16>(x, x2, c1, gamma, beta, residual_in, y, (float*)partials, b, hw, c, groups, act, (hipStream_t)stream);
+    return gn_launch<float>(x, x2, c1, gamma, beta, residual_in, y, (float*)partials, b, hw, c, groups, act, (hipStream_t)stream);
+}

@@ -1,0 +1,206 @@
+"""Host-side plan builder for the HIP kernels.
+
+A *plan* is the static list of C-ABI calls one network forward (or one sampler step) needs for a
+fixed (batch, image size, dtype): buffers are carved from an arena once, every launch argument
+is frozen, and the list is either replayed call by call or captured into a hipGraph and replayed
+as one launch.  PyTorch supplies device memory (the arena's backing tensors) and the stream; all
+arithmetic runs in ``libadvshadow_hip.so``.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ACT, BF16, F32, ConvArgs, check
+
+TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16}
+ESZ = {F32: 4, BF16: 2}
+SLAB_ELEMS = {F32: 32, BF16: 64}       # conv K-slab: 128 bytes of channels
+
+
+def dtype_code(name):
+    if name in (F32, "fp32", "f32", "float32", torch.float32):
+        return F32
+    if name in (BF16, "bf16", "bfloat16", torch.bfloat16):
+        return BF16
+    raise ValueError(f"unsupported compute dtype {name!r} (use 'fp32' or 'bf16')")
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+class Arena:
+    """Best-fit pool of device buffers with explicit release (plans are static, single stream)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.free_list = []           # list of uint8 tensors
+        self.total = 0
+
+    def alloc(self, nbytes):
+        nbytes = (int(nbytes) + 255) // 256 * 256
+        best = None
+        for i, t in enumerate(self.free_list):
+            n = t.numel()
+            if n >= nbytes and n <= 2 * nbytes + 4096 and (best is None or n < self.free_list[best].numel()):
+                best = i
+        if best is not None:
+            return self.free_list.pop(best)
+        self.total += nbytes
+        return torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+
+    def release(self, base):
+        self.free_list.append(base)
+
+
+class Plan:
+    """Frozen launch list + optional hipGraph."""
+
+    def __init__(self, stream):
+        self.ops = []                 # (cfunc, args)
+        self.keep = []                # objects that must outlive the plan (arg structs, tensors)
+        self.stream = stream          # torch.cuda.Stream
+        self.graph = None
+
+    def add(self, fn, *args, keep=()):
+        self.ops.append((fn, args))
+        self.keep.extend(keep)
+
+    def run_eager(self):
+        s = self.stream.cuda_stream
+        for fn, args in self.ops:
+            rc = fn(*args, s)
+            if rc != 0:
+                check(rc, fn.__name__)
+
+    def capture(self):
+        lib = _lib.load()
+        s = self.stream.cuda_stream
+        check(lib.advs_graph_begin(s), "graph_begin")
+        try:
+            self.run_eager()
+        finally:
+            g = C.c_void_p()
+            rc = lib.advs_graph_end(s, C.byref(g))
+        check(rc, "graph_end")
+        self.graph = g
+
+    def run(self):
+        if self.graph is not None:
+            check(_lib.load().advs_graph_launch(self.graph, self.stream.cuda_stream), "graph_launch")
+        else:
+            self.run_eager()
+
+    def __del__(self):
+        try:
+            if self.graph is not None:
+                _lib.load().advs_graph_destroy(self.graph)
+        except Exception:
+            pass
+
+
+class Builder:
+    """Emits kernel calls into a Plan; owns the arena the activations live in."""
+
+    def __init__(self, device, dtype, stream, batch):
+        _lib.init_device()
+        self.lib = _lib.load()
+        self.device = device
+        self.dt = dtype_code(dtype)
+        self.tdt = TORCH_DT[self.dt]
+        self.B = batch
+        self.arena = Arena(device)
+        self.plan = Plan(stream)
+        self._base = {}
+        nb = self.lib.advs_groupnorm_scratch_bytes(batch, 64)
+        self.gn_scratch = torch.empty(nb, dtype=torch.uint8, device=device)
+
+    # ---- buffers
+    def buf(self, shape, dtype=None):
+        dtype = dtype or self.tdt
+        n = 1
+        for s in shape:
+            n *= int(s)
+        base = self.arena.alloc(n * torch.empty((), dtype=dtype).element_size())
+        t = base.view(dtype)[:n].view(*shape)
+        self._base[t.data_ptr()] = base
+        self.plan.keep.append(base)
+        return t
+
+    def free(self, t):
+        base = self._base.pop(t.data_ptr(), None)
+        if base is not None:
+            self.arena.release(base)
+
+    # ---- ops (activations are NHWC tensors [B,H,W,C] of the compute dtype)
+    def conv(self, x1, w, cout, *, x2=None, bias=None, temb=None, temb_stride=0, residual=None,
+             ksize=3, stride=1, pad=1, upsample=False, act=None, out=None):
+        B, H, W, C1 = x1.shape
+        C2 = 0 if x2 is None else x2.shape[3]
+        HL, WL = (H * 2, W * 2) if upsample else (H, W)
+        Ho = (HL + 2 * pad - ksize) // stride + 1
+        Wo = (WL + 2 * pad - ksize) // stride + 1
+        y = out if out is not None else self.buf((B, Ho, Wo, cout))
+        a = ConvArgs(ptr(x1), ptr(x2), ptr(w), ptr(bias), ptr(temb), ptr(residual), ptr(y),
+                     B, H, W, C1, C2, cout, ksize, stride, pad, 1 if upsample else 0,
+                     ACT[act], self.dt, temb_stride)
+        self.plan.add(self.lib.advs_conv2d, C.byref(a), keep=(a, x1, x2, w, bias, temb, residual, y))
+        return y
+
+    def conv_first(self, x_nchw, w, bias, cout):
+        B, Cin, H, W = x_nchw.shape
+        y = self.buf((B, H, W, cout))
+        self.plan.add(self.lib.advs_conv3x3_first, ptr(x_nchw), ptr(w), ptr(bias), ptr(y), B, Cin, H, W, cout, self.dt,
+                      keep=(x_nchw, w, bias, y))
+        return y
+
+    def conv_last(self, x, w, bias, cout, ksize, out_nchw):
+        B, H, W, Cin = x.shape
+        self.plan.add(self.lib.advs_conv_last, ptr(x), ptr(w), ptr(bias), ptr(out_nchw), B, Cin, H, W, cout, ksize, self.dt,
+                      keep=(x, w, bias, out_nchw))
+        return out_nchw
+
+    def groupnorm(self, x, gamma, beta, groups, act=None, x2=None, residual=None):
+        B, H, W, C1 = x.shape
+        C2 = 0 if x2 is None else x2.shape[3]
+        y = self.buf((B, H, W, C1 + C2))
+        self.plan.add(self.lib.advs_groupnorm, ptr(x), ptr(x2), ptr(gamma), ptr(beta), ptr(residual), ptr(y),
+                      ptr(self.gn_scratch), B, H * W, C1, C2, groups, ACT[act], self.dt,
+                      keep=(x, x2, gamma, beta, residual, y))
+        return y
+
+    def attention(self, qkv, heads, d, q_off, k_off, v_off, head_stride):
+        B, H, W, LD = qkv.shape
+        y = self.buf((B, H, W, heads * d))
+        self.plan.add(self.lib.advs_attention, ptr(qkv), ptr(y), B, H * W, heads, d, LD, q_off, k_off, v_off,
+                      head_stride, self.dt, keep=(qkv, y))
+        return y
+
+    def linear(self, x, w, bias, act_in=None, act_out=None):
+        Bn, K = x.shape
+        N = w.shape[0]
+        y = self.buf((Bn, N), torch.float32)
+        self.plan.add(self.lib.advs_linear_f32, ptr(x), ptr(w), ptr(bias), ptr(y), Bn, K, N, ACT[act_in], ACT[act_out],
+                      keep=(x, w, bias, y))
+        return y
+
+    def timestep_embedding(self, t, freqs, cos_first, table=None, labels=None):
+        half = freqs.numel()
+        y = self.buf((self.B, 2 * half), torch.float32)
+        self.plan.add(self.lib.advs_timestep_embedding, ptr(t), ptr(freqs), half, 1 if cos_first else 0, ptr(table),
+                      ptr(labels), ptr(y), self.B, keep=(t, freqs, table, labels, y))
+        return y
+
+
+def pack_conv_weight(w, dt, stream=None):
+    """torch OIHW f32 (device) -> [O][R][S][I] in the compute dtype, on the current stream."""
+    lib = _lib.load()
+    w = w.detach().contiguous().float()
+    O, I, R, S = w.shape
+    out = torch.empty((O, R, S, I), dtype=TORCH_DT[dt], device=w.device)
+    s = (stream or torch.cuda.current_stream(w.device)).cuda_stream
+    check(lib.advs_pack_conv_weight(w.data_ptr(), out.data_ptr(), O, I, R, S, dt, s), "pack_conv_weight")
+    # w must stay alive until the kernel ran; same-stream ordering + sync keeps it simple
+    torch.cuda.current_stream(w.device).synchronize() if stream is None else stream.synchronize()
+    return out

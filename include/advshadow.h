@@ -1,0 +1,143 @@
+/*
+ * advshadow.h — C ABI of libadvshadow_hip.so: the MI355X (gfx950) kernels behind the
+ * AdvShadow hot path (DDIM reverse sampling through the UNet eps-predictor, shadow
+ * composite, victim forward, ASR/PSNR/SSIM reduction).
+ *
+ * The reference is pure Python/PyTorch; the "FFI" a maintainer would bind is the set of
+ * torch ops its modules call.  Every entry point below names the reference call site it
+ * replaces (paths relative to the reference tree).  Conventions:
+ *   - plain pointers and sizes only; all tensor pointers are DEVICE pointers owned by the
+ *     caller (e.g. torch tensors' data_ptr()); the library owns nothing but a 4 KiB zero page;
+ *   - activations are NHWC ("channels last": [B][H][W][C]); dtype ADVS_F32 or ADVS_BF16;
+ *   - every call enqueues on the given hipStream_t (passed as void*), never synchronises,
+ *     allocates nothing, and is therefore legal inside stream capture;
+ *   - return 0 on success, a negative ADVS_ERR_* otherwise; advs_last_error() has the text.
+ */
+#ifndef ADVSHADOW_H
+#define ADVSHADOW_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { ADVS_OK = 0, ADVS_ERR_ARG = -1, ADVS_ERR_HIP = -2, ADVS_ERR_STATE = -3 };
+enum { ADVS_F32 = 0, ADVS_BF16 = 1 };
+enum { ADVS_ACT_NONE = 0, ADVS_ACT_RELU = 1, ADVS_ACT_SILU = 2, ADVS_ACT_GELU = 3,
+       ADVS_ACT_RELU6 = 4, ADVS_ACT_LRELU01 = 5, ADVS_ACT_LRELU001 = 6 };
+
+/* ---- library ---------------------------------------------------------------------- */
+int advs_init(void);                    /* allocate the zero page on the current device   */
+const char* advs_last_error(void);
+int advs_abi_version(void);
+
+/* ---- weight packing ------------------------------------------------------------------
+ * nn.Conv2d weight [Cout][Cin][R][S] f32 (torch layout) -> GEMM operand [Cout][R][S][Cin]
+ * in `dtype`.  nn.Linear weight [N][K] is the R=S=1 case.                                */
+int advs_pack_conv_weight(const float* w_oihw, void* w_packed, int cout, int cin, int r, int s,
+                          int dtype, void* stream);
+
+/* ---- layout / dtype conversion ------------------------------------------------------- */
+int advs_nchw_f32_to_nhwc(const float* x, void* y, int b, int c, int h, int w, int dtype, void* stream);
+int advs_nhwc_to_nchw_f32(const void* x, float* y, int b, int c, int h, int w, int dtype, void* stream);
+
+/* ---- Conv2d as implicit GEMM on MFMA ---------------------------------------------------
+ * Replaces nn.Conv2d (3x3 pad 1 stride 1|2, 1x1) at diff_model.py:73,86,90,114,115,134,148,
+ * model/modules/conv.py:38,41, victim convs.  Fusions selected by the descriptor:
+ *   - x2/c2: second source concatenated after x1 on the channel axis (torch.cat,
+ *     diff_model.py:265; model/modules/block.py:87);
+ *   - upsample: nearest x2 applied to the sources on load (F.interpolate, diff_model.py:137);
+ *   - bias[n], temb[b][n] (h += time_emb(t)[:, :, None, None], diff_model.py:101),
+ *     residual[m][n] (h + shortcut(x), diff_model.py:103,127), activation.
+ * Requirements: c1 and c2 multiples of 64 (bf16) / 32 (f32).                               */
+typedef struct advs_conv_args {
+    const void* x1; const void* x2;     /* NHWC sources [b][h][w][c1], [b][h][w][c2]        */
+    const void* w;                      /* packed [cout][r][r][c1+c2]                       */
+    const float* bias;                  /* [cout] or NULL                                   */
+    const float* temb;                  /* row b at temb + b*temb_stride, or NULL           */
+    const void* residual;               /* NHWC [b][ho][wo][cout] or NULL                   */
+    void* y;                            /* NHWC [b][ho][wo][cout]                           */
+    int b, h, w_, c1, c2, cout;         /* h,w_: stored source size (before upsample)       */
+    int ksize, stride, pad, upsample;   /* ksize 1|3; upsample 0|1                          */
+    int act, dtype;
+    int temb_stride;                    /* floats between consecutive samples' temb rows    */
+} advs_conv_args;
+int advs_conv2d(const advs_conv_args* a, void* stream);
+
+/* First conv: NCHW f32 image (cin <= 4) -> NHWC `dtype`, 3x3 pad 1 (diff_model.py:192;
+ * model/modules/conv.py:38 for inc).  w is the torch OIHW f32 weight.                      */
+int advs_conv3x3_first(const float* x_nchw, const float* w_oihw, const float* bias, void* y,
+                       int b, int cin, int h, int w, int cout, int dtype, void* stream);
+/* Last conv: NHWC `dtype` (cin multiple of 8) -> NCHW f32 with cout <= 4 (diff_model.py:242,
+ * ksize 3; model/networks/unet.py:92, ksize 1).  w is the torch OIHW f32 weight.           */
+int advs_conv_last(const void* x, const float* w_oihw, const float* bias, float* y_nchw,
+                   int b, int cin, int h, int w, int cout, int ksize, int dtype, void* stream);
+
+/* ---- GroupNorm (+activation) ---------------------------------------------------------
+ * nn.GroupNorm(G, C) followed by an optional activation (norm_layer+SiLU, diff_model.py:62-63,
+ * 71-72,83-84,113,240-241; GroupNorm(1, C)+act, model/modules/conv.py:39-42).  eps = 1e-5.
+ * `partials` is caller scratch of advs_groupnorm_scratch_bytes(b, groups) bytes.
+ * Optional residual_in: y = act(residual_in + GN(x)) (DoubleConv residual, conv.py:53).     */
+size_t advs_groupnorm_scratch_bytes(int b, int groups);
+/* x2/c2: optional second source concatenated after x on the channel axis (the norm of
+ * torch.cat([h, skip]), diff_model.py:265 -> :71); y is the concatenated [b][hw][c+c2].     */
+int advs_groupnorm(const void* x, const void* x2, const float* gamma, const float* beta,
+                   const void* residual_in, void* y, void* partials, int b, int hw, int c, int c2,
+                   int groups, int act, int dtype, void* stream);
+
+/* ---- self-attention, flash style -------------------------------------------------------
+ * softmax(q k^T / sqrt(d)) v per (batch, head) without materialising the N x N scores
+ * (AttentionBlock.forward, diff_model.py:120-125; nn.MultiheadAttention core,
+ * model/modules/attention.py:50).  qkv is [b][n][ld] (row = token); head hd takes
+ * q/k/v at column q_off/k_off/v_off + hd*head_stride, d columns each.  out is [b][n][heads*d].
+ * n multiple of 32, d multiple of 16, d <= 128.                                          */
+int advs_attention(const void* qkv, void* out, int b, int n, int heads, int d, int ld,
+                   int q_off, int k_off, int v_off, int head_stride, int dtype, void* stream);
+
+/* ---- small dense layers of the time-embedding path (always f32) ------------------------
+ * y[b][n] = bias[n] + sum_k act_in(x[b][k]) * w[n][k]   (nn.Linear after optional SiLU:
+ * diff_model.py:184-188,77-80; model/modules/block.py:33-36).  w is torch layout [n][k].     */
+int advs_linear_f32(const float* x, const float* w, const float* bias, float* y, int b, int k, int n,
+                    int act_in, int act_out, void* stream);
+/* Sinusoidal embedding of t[b] (int64, device) with a host-computed frequency table
+ * freqs[half] (device): out[b] = [cos|sin] (cos_first=1: diff_model.py:16-33) or [sin|cos]
+ * (cos_first=0: model/networks/base.py:56-68).  label_emb rows (or NULL) are added:
+ * out[b] += emb_table[labels[b]] (model/networks/unet.py:106-107).                           */
+int advs_timestep_embedding(const int64_t* t, const float* freqs, int half, int cos_first,
+                            const float* emb_table, const int64_t* labels, float* out, int b,
+                            void* stream);
+
+/* ---- DDIM update -------------------------------------------------------------------------
+ * One reverse step on NCHW f32 x (in place), coefficients read from a device table so the
+ * same captured launch serves every step:
+ *   coef[step] = { a_t, a_prev, sigma }  (f32, host-computed exactly as the reference does)
+ *   eps' = eps_u + cfg*(eps - eps_u) if eps_uncond (torch.lerp, model/samples/ddim.py:89)
+ *   x0 = clamp((x - sqrt(1-a_t) eps')/sqrt(a_t), -1, 1); x = sqrt(a_prev) x0 + sqrt(1-a_prev-sigma^2) eps' + sigma*noise
+ * (diff_model.py:457-470, model/samples/ddim.py:91-94).  *step_counter (device int32) selects the
+ * row, is written to t_out[b] as the NEXT step's timestep from tseq, and is incremented.     */
+int advs_ddim_step(float* x, const float* eps, const float* eps_uncond, float cfg_scale,
+                   const float* noise, const float* coef, const int64_t* tseq, int nsteps,
+                   int32_t* step_counter, int64_t* t_out, int b, size_t per_sample, int clip,
+                   void* stream);
+/* uint8 image = trunc((x+1)*0.5*255) wrapped mod 256 (no clamp: model/samples/ddim.py:97-99),
+ * or clamped when clamp != 0.                                                                */
+int advs_to_uint8(const float* x, uint8_t* y, size_t n, int clamp, void* stream);
+
+/* ---- stream capture (hipGraph) -------------------------------------------------------- */
+int advs_graph_begin(void* stream);
+int advs_graph_end(void* stream, void** graph_exec_out);
+int advs_graph_launch(void* graph_exec, void* stream);
+int advs_graph_destroy(void* graph_exec);
+
+/* ---- timing helpers for bench.py (HIP events on the engine's own stream) ----------------- */
+int advs_event_create(void** ev);
+int advs_event_record(void* ev, void* stream);
+int advs_event_elapsed_ms(void* start, void* stop, float* ms);   /* synchronises on stop */
+int advs_event_destroy(void* ev);
+int advs_stream_sync(void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADVSHADOW_H */

@@ -1,0 +1,291 @@
+"""Per-kernel parity on the MI355X: every C-ABI op against the same op restated with torch CPU
+fp32 functional calls (the op-level oracle).  f32 mode must agree to fp32 rounding
+noise; bf16 mode is compared with the reference evaluated on bf16-rounded operands."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from gpu_helpers import OneOp, bf16_round, dev, nchw, nhwc  # noqa: E402
+from advshadow_amd import _lib  # noqa: E402
+from advshadow_amd.engine import pack_conv_weight, dtype_code, ptr  # noqa: E402
+
+DTS = ["fp32", "bf16"]
+
+
+def tol(dt, f32, bf16):
+    return f32 if dt == "fp32" else bf16
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+# ------------------------------------------------------------------------------ conv
+CONV_CASES = [
+    # B, H, W, C1, C2, Cout, k, stride, ups, bias, temb, res, act
+    (2, 12, 12, 64, 0, 128, 3, 1, 0, 1, 0, 0, None),       # M tail (288 rows)
+    (1, 16, 16, 128, 0, 128, 3, 1, 0, 1, 1, 1, None),      # full epilogue
+    (2, 16, 16, 64, 0, 64, 3, 2, 0, 1, 0, 0, None),        # stride 2, N tail (64 < 128)
+    (3, 8, 8, 128, 0, 192, 1, 1, 0, 1, 0, 1, None),        # 1x1, N tail 192, batch 3
+    (1, 8, 8, 64, 0, 128, 3, 1, 1, 1, 0, 0, None),         # nearest x2 on load
+    (2, 8, 8, 64, 128, 128, 3, 1, 0, 1, 1, 0, None),       # concat on load
+    (2, 8, 8, 128, 64, 64, 1, 1, 0, 1, 0, 0, "relu"),      # concat 1x1 + relu
+    (1, 32, 32, 64, 0, 256, 3, 1, 0, 0, 0, 0, "silu"),     # no bias, 2 N tiles, 8 M tiles
+    (1, 14, 14, 256, 0, 64, 1, 2, 0, 1, 0, 0, None),       # 1x1 stride 2 (victim downsample path)
+]
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d(case, dt):
+    B, H, W, C1, C2, Cout, k, stride, ups, has_b, has_t, has_r, act = case
+    pad = 1 if k == 3 else 0
+    x1 = rnd(B, C1, H, W, seed=1)
+    x2 = rnd(B, C2, H, W, seed=2) if C2 else None
+    w = rnd(Cout, C1 + C2, k, k, seed=3, scale=1.0 / math.sqrt((C1 + C2) * k * k))
+    bias = rnd(Cout, seed=4) if has_b else None
+    temb = rnd(B, Cout + 5, seed=5) if has_t else None          # strided rows
+    xin = x1 if x2 is None else torch.cat([x1, x2], 1)
+    if dt == "bf16":
+        xin, wr = bf16_round(xin), bf16_round(w)
+    else:
+        wr = w
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+    ref = F.conv2d(xin, wr, bias, stride=stride, padding=pad)
+    res = rnd(*ref.shape, seed=6) if has_r else None
+    if has_t:
+        ref = ref + temb[:, :Cout, None, None]
+    if has_r:
+        ref = ref + (bf16_round(res) if dt == "bf16" else res)
+    if act == "relu":
+        ref = F.relu(ref)
+    elif act == "silu":
+        ref = F.silu(ref)
+
+    op = OneOp(dt, B)
+    wp = pack_conv_weight(w.to(dev()), dtype_code(dt))
+    tb = temb.to(dev()) if has_t else None
+    y = op.b.conv(nhwc(x1, dt), wp, Cout, x2=nhwc(x2, dt) if C2 else None,
+                  bias=bias.to(dev()) if has_b else None,
+                  temb=tb[:, :Cout] if has_t else None, temb_stride=Cout + 5 if has_t else 0,
+                  residual=nhwc(res, dt) if has_r else None,
+                  ksize=k, stride=stride, pad=pad, upsample=bool(ups), act=act)
+    op.go()
+    got = nchw(y)
+    assert got.shape == ref.shape
+    err = (got - ref).abs().max().item()
+    assert err < tol(dt, 2e-5, 4e-2), err
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_pack_conv_weight(dt):
+    w = rnd(6, 5, 3, 3, seed=9)
+    p = pack_conv_weight(w.to(dev()), dtype_code(dt)).float().cpu()
+    ref = w.permute(0, 2, 3, 1)
+    ref = bf16_round(ref) if dt == "bf16" else ref
+    assert torch.equal(p, ref.contiguous())
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("shape", [(2, 3, 16, 16, 64), (1, 3, 9, 13, 128), (1, 1, 8, 8, 32)])
+def test_conv_first(shape, dt):
+    B, Cin, H, W, Cout = shape
+    x, w, b = rnd(B, Cin, H, W, seed=1), rnd(Cout, Cin, 3, 3, seed=2, scale=0.2), rnd(Cout, seed=3)
+    ref = F.conv2d(x, w, b, padding=1)
+    op = OneOp(dt, B)
+    y = op.b.conv_first(x.to(dev()), w.to(dev()), b.to(dev()), Cout)
+    op.go()
+    err = (nchw(y) - ref).abs().max().item()
+    assert err < tol(dt, 1e-5, 3e-2), err
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("shape", [(2, 64, 16, 16, 3, 3), (1, 128, 9, 13, 3, 3), (2, 64, 8, 8, 3, 1), (1, 32, 8, 8, 1, 3)])
+def test_conv_last(shape, dt):
+    B, Cin, H, W, Cout, k = shape
+    x, w, b = rnd(B, Cin, H, W, seed=1), rnd(Cout, Cin, k, k, seed=2, scale=0.1), rnd(Cout, seed=3)
+    xr = bf16_round(x) if dt == "bf16" else x
+    ref = F.conv2d(xr, w, b, padding=k // 2)
+    op = OneOp(dt, B)
+    out = torch.empty(B, Cout, H, W, device=dev())
+    op.b.conv_last(nhwc(x, dt), w.to(dev()), b.to(dev()), Cout, k, out)
+    op.go()
+    err = (out.cpu() - ref).abs().max().item()
+    assert err < 2e-5, err
+
+
+# ------------------------------------------------------------------------------ groupnorm
+GN_CASES = [
+    # B, H, W, C1, C2, G, act, residual
+    (2, 8, 8, 64, 0, 32, "silu", 0),
+    (1, 32, 32, 128, 0, 32, "silu", 0),
+    (2, 16, 16, 128, 64, 32, "silu", 0),      # 192 ch: groups of 6 straddle the two sources
+    (3, 16, 16, 256, 128, 32, None, 0),
+    (2, 8, 8, 64, 0, 1, "gelu", 0),           # GroupNorm(1, C) of DoubleConv
+    (1, 16, 16, 128, 0, 1, "silu", 1),        # residual DoubleConv: act(x + GN(.))
+    (1, 64, 64, 64, 0, 32, None, 0),
+    (1, 8, 8, 512, 0, 32, "silu", 0),
+]
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("case", GN_CASES)
+def test_groupnorm(case, dt):
+    B, H, W, C1, C2, G, act, has_r = case
+    C = C1 + C2
+    x1, x2 = rnd(B, C1, H, W, seed=1) * 2 + 0.5, (rnd(B, C2, H, W, seed=2) - 1.0) if C2 else None
+    gamma, beta = rnd(C, seed=3) * 0.5 + 1, rnd(C, seed=4) * 0.2
+    res = rnd(B, C, H, W, seed=5) if has_r else None
+    xin = x1 if x2 is None else torch.cat([x1, x2], 1)
+    if dt == "bf16":
+        xin = bf16_round(xin)
+    ref = F.group_norm(xin, G, gamma, beta, eps=1e-5)
+    if has_r:
+        ref = ref + (bf16_round(res) if dt == "bf16" else res)
+    ref = {"silu": F.silu, "gelu": F.gelu, None: lambda v: v}[act](ref)
+    op = OneOp(dt, B)
+    y = op.b.groupnorm(nhwc(x1, dt), gamma.to(dev()), beta.to(dev()), G, act=act,
+                       x2=nhwc(x2, dt) if C2 else None, residual=nhwc(res, dt) if has_r else None)
+    op.go()
+    err = (nchw(y) - ref).abs().max().item()
+    assert err < tol(dt, 2e-5, 3e-2), err
+
+
+def test_groupnorm_is_batch_invariant():
+    """A sample's result must not depend on its batch (shard equality across GPUs)."""
+    x = rnd(4, 128, 16, 16, seed=7)
+    gamma, beta = torch.ones(128), torch.zeros(128)
+    outs = []
+    for sl in (slice(0, 4), slice(2, 3)):
+        op = OneOp("fp32", x[sl].shape[0])
+        y = op.b.groupnorm(nhwc(x[sl], "fp32"), gamma.to(dev()), beta.to(dev()), 32, act="silu")
+        op.go()
+        outs.append(nchw(y))
+    assert torch.equal(outs[0][2:3], outs[1])
+
+
+# ------------------------------------------------------------------------------ attention
+ATT_CASES = [
+    # B, N, heads, d, layout
+    (2, 64, 4, 64, "b"), (1, 256, 4, 32, "b"), (1, 1024, 4, 64, "b"), (2, 64, 2, 96, "b"),
+    (1, 256, 2, 128, "b"), (1, 1024, 2, 32, "b"), (2, 256, 4, 16, "a"), (1, 64, 4, 64, "a"),
+]
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("case", ATT_CASES)
+def test_attention(case, dt):
+    B, N, heads, d, lay = case
+    C = heads * d
+    qkv = rnd(B, N, 3 * C, seed=11)
+    if dt == "bf16":
+        qkv = bf16_round(qkv)
+    if lay == "b":      # per head [q|k|v] interleave (diff_model.py:120)
+        t = qkv.view(B, N, heads, 3, d)
+        q, k, v = t[:, :, :, 0], t[:, :, :, 1], t[:, :, :, 2]
+        offs = (0, d, 2 * d, 3 * d)
+    else:               # in_proj layout: [Q(C) | K(C) | V(C)], head h at h*d
+        t = qkv.view(B, N, 3, heads, d)
+        q, k, v = t[:, :, 0], t[:, :, 1], t[:, :, 2]
+        offs = (0, C, 2 * C, d)
+    q, k, v = (u.permute(0, 2, 1, 3) for u in (q, k, v))          # [B, heads, N, d]
+    w = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(d), dim=-1)
+    ref = (w @ v).permute(0, 2, 1, 3).reshape(B, N, C)
+    op = OneOp(dt, B)
+    side = int(math.isqrt(N))
+    x = qkv.view(B, side, side, 3 * C).to(dev(), torch.bfloat16 if dt == "bf16" else torch.float32)
+    y = op.b.attention(x, heads, d, *offs)
+    op.go()
+    got = y.float().cpu().view(B, N, C)
+    err = (got - ref).abs().max().item()
+    assert err < tol(dt, 2e-5, 3e-2), err
+
+
+# ------------------------------------------------------------------------------ small ops
+def test_linear_and_embedding():
+    lib = _lib.load()
+    _lib.init_device()
+    s = torch.cuda.current_stream().cuda_stream
+    x, w, b = rnd(3, 128, seed=1), rnd(512, 128, seed=2, scale=0.1), rnd(512, seed=3)
+    y = torch.empty(3, 512, device=dev())
+    xd, wd, bd = x.to(dev()), w.to(dev()), b.to(dev())
+    _lib.check(lib.advs_linear_f32(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), 3, 128, 512, 2, 2, s))
+    ref = F.silu(F.linear(F.silu(x), w, b))
+    assert (y.cpu() - ref).abs().max().item() < 1e-5
+    # sinusoidal embeddings, both orders, with a label table
+    t = torch.tensor([1, 501, 981], dtype=torch.int64)
+    half = 64
+    freqs = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half)
+    table, labels = rnd(37, 128, seed=4), torch.tensor([0, 36, 17])
+    out = torch.empty(3, 128, device=dev())
+    td, fd, tabd, lbd = t.to(dev()), freqs.to(dev()), table.to(dev()), labels.to(dev())
+    _lib.check(lib.advs_timestep_embedding(td.data_ptr(), fd.data_ptr(), half, 1, 0, 0, out.data_ptr(), 3, s))
+    args = t[:, None].float() * freqs[None]
+    assert (out.cpu() - torch.cat([args.cos(), args.sin()], -1)).abs().max().item() < 2e-6
+    _lib.check(lib.advs_timestep_embedding(td.data_ptr(), fd.data_ptr(), half, 0, tabd.data_ptr(), lbd.data_ptr(),
+                                           out.data_ptr(), 3, s))
+    assert (out.cpu() - (torch.cat([args.sin(), args.cos()], -1) + table[labels])).abs().max().item() < 2e-6
+
+
+@pytest.mark.parametrize("cfg", [None, 3.0, 0.3])
+def test_ddim_step_bit_exact(cfg):
+    """The fused update must round exactly like the reference's chain of torch ops."""
+    lib = _lib.load()
+    _lib.init_device()
+    s = torch.cuda.current_stream().cuda_stream
+    B, per = 2, 3 * 16 * 16
+    x, eps, eu, nz = rnd(B, per, seed=1), rnd(B, per, seed=2), rnd(B, per, seed=3), rnd(B, per, seed=4)
+    a_t, a_p = torch.tensor(0.3712, dtype=torch.float32), torch.tensor(0.5521, dtype=torch.float32)
+    sig = 0.7 * torch.sqrt((1 - a_p) / (1 - a_t) * (1 - a_t / a_p))
+    coef = torch.stack([torch.tensor([0.9, 0.95, 0.0]), torch.stack([a_t, a_p, sig])]).float()
+    tseq = torch.tensor([981, 961], dtype=torch.int64)
+    e = eps if cfg is None else torch.lerp(eu, eps, cfg)
+    x0 = torch.clamp((x - torch.sqrt(1.0 - a_t) * e) / torch.sqrt(a_t), -1.0, 1.0)
+    ref = torch.sqrt(a_p) * x0 + torch.sqrt(1 - a_p - sig ** 2) * e + sig * nz
+    xd, ed, ud, nd = x.to(dev()), eps.to(dev()), eu.to(dev()), nz.to(dev())
+    cd, td = coef.to(dev()), tseq.to(dev())
+    counter = torch.ones(1, dtype=torch.int32, device=dev())       # row 1
+    tout = torch.zeros(B, dtype=torch.int64, device=dev())
+    _lib.check(lib.advs_ddim_step(xd.data_ptr(), ed.data_ptr(), ud.data_ptr() if cfg is not None else 0,
+                                  float(cfg or 0.0), nd.data_ptr(), cd.data_ptr(), td.data_ptr(), 2,
+                                  counter.data_ptr(), tout.data_ptr(), B, per, 1, s))
+    torch.cuda.synchronize()
+    assert torch.equal(xd.cpu(), ref)
+    assert counter.item() == 2 and tout.tolist() == [961, 961]
+
+
+def test_to_uint8_wraps_like_torch_cpu():
+    lib = _lib.load()
+    _lib.init_device()
+    x = torch.tensor([-1.02, -1.0, -0.999, 0.0, 0.5, 0.999, 1.0, 1.004, 1.03, -1.3], dtype=torch.float32)
+    ref = (((x + 1) * 0.5) * 255).type(torch.uint8)
+    xd = x.to(dev())
+    y = torch.empty(x.numel(), dtype=torch.uint8, device=dev())
+    _lib.check(lib.advs_to_uint8(xd.data_ptr(), y.data_ptr(), x.numel(), 0, torch.cuda.current_stream().cuda_stream))
+    assert torch.equal(y.cpu(), ref)
+    _lib.check(lib.advs_to_uint8(xd.data_ptr(), y.data_ptr(), x.numel(), 1, torch.cuda.current_stream().cuda_stream))
+    assert torch.equal(y.cpu(), (((x + 1) * 0.5) * 255).clamp(0, 255).type(torch.uint8))
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_layout_roundtrip(dt):
+    lib = _lib.load()
+    _lib.init_device()
+    s = torch.cuda.current_stream().cuda_stream
+    x = rnd(2, 37, 9, 11, seed=3)
+    xd = x.to(dev())
+    y = torch.empty(2, 9, 11, 37, dtype=torch.bfloat16 if dt == "bf16" else torch.float32, device=dev())
+    z = torch.empty_like(xd)
+    code = dtype_code(dt)
+    _lib.check(lib.advs_nchw_f32_to_nhwc(xd.data_ptr(), y.data_ptr(), 2, 37, 9, 11, code, s))
+    _lib.check(lib.advs_nhwc_to_nchw_f32(y.data_ptr(), z.data_ptr(), 2, 37, 9, 11, code, s))
+    ref = bf16_round(x) if dt == "bf16" else x
+    assert torch.equal(y.float().cpu(), ref.permute(0, 2, 3, 1).contiguous())
+    assert torch.equal(z.cpu(), ref)
