@@ -1,0 +1,196 @@
+#!/usr/bin/env python
+"""Headline benchmark: shadow-images/sec, 256x256, 50-step DDIM (BASELINE.json configs[1]).
+
+One *step* = one full pass of the hot path over one batch: B images of 3x256x256 sampled with
+``GaussianDiffusion.ddim_sample`` (50 UNetModel forwards + 50 fused DDIM updates), bf16
+activations/weights with f32 accumulation, x_T already resident in HBM.  One process per GPU;
+N > 1 shards independent image batches across ranks (weak scaling, no data-path collective).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with a `roofline` object for the
+dominant kernel (the implicit-GEMM conv, MFMA-bound) measured with HIP events on the engine's
+stream, and a `cpu_baseline` object (the CPU oracle timed on the host cores, N=1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_MFMA_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}     # MI355X_MICROARCH.md: dense peaks
+
+
+def conv_profile(eng, reps=2):
+    """Time every launch of the plan with HIP events on the engine's stream (eager replay) and
+    return per-kernel totals: {entry point: [launches, total ms, algorithmic flops]}."""
+    from advshadow_amd import _lib
+    lib = _lib.load()
+    s = eng.stream.cuda_stream
+    ops = eng.plan.ops
+    evs = []
+    for _ in range(len(ops) + 1):
+        e = C.c_void_p()
+        _lib.check(lib.advs_event_create(C.byref(e)))
+        evs.append(e)
+    totals = {}
+    for rep in range(reps + 1):
+        eng.stream.synchronize()
+        _lib.check(lib.advs_event_record(evs[0], s))
+        for i, (fn, args) in enumerate(ops):
+            _lib.check(fn(*args, s), fn.__name__)
+            _lib.check(lib.advs_event_record(evs[i + 1], s))
+        eng.stream.synchronize()
+        if rep == 0:
+            continue                                            # warm-up pass
+        for i, (fn, args) in enumerate(ops):
+            ms = C.c_float()
+            _lib.check(lib.advs_event_elapsed_ms(evs[i], evs[i + 1], C.byref(ms)))
+            t = totals.setdefault(fn.__name__, [0, 0.0, 0.0])
+            t[0] += 1
+            t[1] += ms.value
+            if fn.__name__ == "advs_conv2d":
+                a = args[0]._obj
+                hl, wl = (a.h * 2, a.w_ * 2) if a.upsample else (a.h, a.w_)
+                ho = (hl + 2 * a.pad - a.ksize) // a.stride + 1
+                wo = (wl + 2 * a.pad - a.ksize) // a.stride + 1
+                t[2] += 2.0 * a.b * ho * wo * a.cout * a.ksize * a.ksize * (a.c1 + a.c2)
+    for e in evs:
+        lib.advs_event_destroy(e)
+    for t in totals.values():
+        t[0] //= reps
+        t[1] /= reps
+        t[2] /= reps
+    return totals
+
+
+def cpu_baseline(size, ddim_steps, budget_s=20.0):
+    """The CPU oracle (oracle/lineage_b.py, torch-CPU fp32) on the host cores: B=1 forwards of the
+    same network at the same resolution, extrapolated to a full ddim_steps-step image."""
+    from oracle import lineage_b as ob
+    try:
+        cores = len(os.sched_getaffinity(0))                    # the cores this process may use
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    hp = ob.hparams()
+    sd = ob.init_state_dict(0, hp)
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(1, 3, size, size, generator=g)
+    t = torch.full((1,), 501, dtype=torch.long)
+    ob.unet_forward(sd, hp, x, t)                               # warm-up
+    n, t0 = 0, time.time()
+    while n < 2 or (time.time() - t0 < budget_s and n < 50):
+        ob.unet_forward(sd, hp, x, t)
+        n += 1
+    per_fwd = (time.time() - t0) / n
+    return {"value": 1.0 / (per_fwd * ddim_steps), "unit": "shadow-images/sec",
+            "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} UNetModel forwards, B=1, {size}x{size}, fp32 torch-CPU oracle; "
+                      f"{per_fwd:.3f} s/forward x {ddim_steps} steps per image"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--ddim-steps", type=int, default=50)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        args.gpus = world
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from advshadow_amd.diff_model import GaussianDiffusion, UNetModel
+
+    torch.manual_seed(0)                                        # random-init weights of the named architecture
+    net = UNetModel(compute_dtype=args.dtype).to(dev).eval()
+    gd = GaussianDiffusion()                                    # cosine schedule (diff_model.py:290)
+    B, S = args.batch, args.size
+    g = torch.Generator().manual_seed(1234 + rank)              # images are indexed globally: rank r owns [r*B, (r+1)*B)
+    xT = torch.randn(B, 3, S, S, generator=g).to(dev)
+
+    def one_pass():
+        return gd.ddim_sample(net, S, batch_size=B, ddim_timesteps=args.ddim_steps, x_T=xT, return_tensor=True)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        one_pass()
+    if args.warmup == 0:
+        net.engine(B, S)                                        # build the plan outside the timed region
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_pass()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(out).all().item(), "non-finite samples"
+
+    line = {
+        "metric": "shadow-images/sec @256x256 50-step DDIM",
+        "value": world * B * args.steps / elapsed,
+        "unit": "shadow-images/sec",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"DDIM-{args.ddim_steps} shadow generation, diff_model.UNetModel() defaults "
+                               f"(35.7M params, random init seed 0), batch {B}/GPU, 3x{S}x{S}, cosine schedule, "
+                               f"x_T resident in HBM, hipGraph-captured step",
+                   "batch_per_gpu": B, "image_size": S, "ddim_steps": args.ddim_steps,
+                   "parallelism": f"batch-shard x{world}"},
+    }
+    if rank == 0 and not args.no_roofline:
+        eng = net.engine(B, S)
+        tot = conv_profile(eng)
+        c = tot["advs_conv2d"]
+        fwd_ms = sum(t[1] for t in tot.values())
+        ach = c[2] / (c[1] * 1e-3) / 1e12
+        peak = PEAK_MFMA_TFLOPS[args.dtype]
+        line["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel", "achieved": ach, "peak": peak,
+                            "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                            "launches_per_forward": c[0], "avg_launch_ms": c[1] / c[0],
+                            "algorithmic_gflop_per_launch": c[2] / c[0] / 1e9,
+                            "forward_ms_by_kernel": {k: round(v[1], 3) for k, v in sorted(tot.items())},
+                            "forward_ms_total": round(fwd_ms, 3)}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(S, args.ddim_steps)
+    if rank == 0:
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
