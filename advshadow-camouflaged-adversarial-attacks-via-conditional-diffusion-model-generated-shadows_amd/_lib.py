@@ -20,7 +20,7 @@ class ConvArgs(C.Structure):
     _fields_ = [("x1", vp), ("x2", vp), ("w", vp), ("bias", vp), ("temb", vp), ("residual", vp), ("y", vp),
                 ("b", i32), ("h", i32), ("w_", i32), ("c1", i32), ("c2", i32), ("cout", i32),
                 ("ksize", i32), ("stride", i32), ("pad", i32), ("upsample", i32),
-                ("act", i32), ("dtype", i32), ("temb_stride", i32)]
+                ("act", i32), ("dtype", i32), ("temb_stride", i32), ("tile", i32)]
 
 
 # name -> argtypes (restype is int unless listed in _RESTYPES)
@@ -31,6 +31,7 @@ SIGNATURES = {
     "advs_nchw_f32_to_nhwc": [vp, vp, i32, i32, i32, i32, i32, vp],
     "advs_nhwc_to_nchw_f32": [vp, vp, i32, i32, i32, i32, i32, vp],
     "advs_conv2d": [C.POINTER(ConvArgs), vp],
+    "advs_conv_set_tile": [i32],
     "advs_conv3x3_first": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "advs_conv_last": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "advs_groupnorm": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],

@@ -8,20 +8,19 @@
 // global_load_lds (16 B per lane, per-lane source address = the im2col gather).  The gather
 // also performs the channel concat of two sources and the nearest x2 upsample.
 //
-// Tile: 128(M) x 128(N) x 128 B of K per step; 4 waves, each a 64x64 block of 2x2 MFMA
-// 32x32 tiles.  bf16: v_mfma_f32_32x32x16_bf16; f32: v_mfma_f32_32x32x2_f32 (exact f32).
-// LDS: double-buffered A and B tiles (64 KiB), rows of 128 B with the 16-byte chunk index
-// XOR-ed by (row>>1)&7 so every ds_read_b128 of a fragment is bank-conflict free; since the
-// DMA writes LDS linearly the same XOR is applied to the per-lane SOURCE address.
+// Tile BM x BN x 128 B of K per step, NW waves each owning a WM x WN block of 32x32 MFMA
+// tiles.  bf16: v_mfma_f32_32x32x16_bf16; f32: v_mfma_f32_32x32x2_f32 (exact f32).
+// LDS: double-buffered A and B tiles, rows of 128 B with the 16-byte chunk index XOR-ed by
+// (row>>1)&7 so every ds_read_b128 of a fragment is bank-conflict free; since the DMA writes
+// LDS linearly the same XOR is applied to the per-lane SOURCE address.
+// Epilogue: each wave transposes its accumulators through a private LDS patch so that bias /
+// temb / residual are read and y is written as 16-byte vectors along the channel axis
+// (whole 128-byte lines), instead of one element per lane.
 //
 // Roofline: MFMA-bound.  Algorithmic FLOPs per launch = 2*M*N*K.
 #include "common.h"
 
-#define BM 128
-#define BN 128
 #define SLAB 128                 // bytes of K per row per step
-#define TILE_BYTES (BM * SLAB)   // 16 KiB per operand tile
-#define NTHREADS 256
 
 struct ConvKP {
     const char* x1; const char* x2; const char* w;
@@ -59,12 +58,19 @@ template <> struct Mma<float> {
     }
 };
 
-template <typename T>
-__global__ void __launch_bounds__(NTHREADS)
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
 conv_igemm_kernel(const ConvKP p) {
     constexpr int ESZ = Mma<T>::ESZ;
+    constexpr int VEC = 16 / ESZ;
     constexpr int BKE = SLAB / ESZ;                       // K elements per slab
-    __shared__ __attribute__((aligned(1024))) char smem[4 * TILE_BYTES];   // A0 B0 A1 B1
+    constexpr int NWN = BN / WN, NW = (BM / WM) * NWN, NT = NW * 64;
+    constexpr int AR = BM * 8 / NT, BR = BN * 8 / NT;     // 16-byte chunks each lane stages per slab
+    constexpr int TM = WM / 32, TN = WN / 32;             // MFMA tiles per wave
+    constexpr int A_BYTES = BM * SLAB, B_BYTES = BN * SLAB, STAGE = A_BYTES + B_BYTES;
+    static_assert(AR * NT == BM * 8 && BR * NT == BN * 8, "tile/wave geometry");
+    static_assert(NW * 32 * WN * 4 <= 2 * STAGE, "epilogue patches must fit the staging buffers");
+    extern __shared__ __attribute__((aligned(1024))) char smem[];   // [2][A tile | B tile]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -80,18 +86,18 @@ conv_igemm_kernel(const ConvKP p) {
     const int mt = bid / p.nNt, nt = bid - mt * p.nNt;
     const int m0 = mt * BM, n0 = nt * BN;
 
-    // ---- per-lane staging geometry: 4 A rows and 4 B rows per lane, one 16-B chunk each
+    // ---- per-lane staging geometry: AR rows of A and BR rows of B per lane, one 16-B chunk each
     const int HoWo = p.Ho * p.Wo;
     const int Cin = p.C1 + p.C2;
     const int HL = p.H << p.ups, WL = p.W << p.ups;
     const int chunk = lane & 7;
-    int a_b[4], a_iy[4], a_ix[4];
-    int csw[4];                                          // swizzled chunk byte offset
-    const char* b_src[4];
+    int a_b[AR], a_iy[AR], a_ix[AR], a_csw[AR];
+    const char* b_src[BR];
+    int b_csw[BR];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = (wave * 4 + j) * 8 + (lane >> 3);
-        csw[j] = ((chunk ^ ((row >> 1) & 7)) << 4);
+    for (int j = 0; j < AR; ++j) {
+        const int row = (wave * AR + j) * 8 + (lane >> 3);
+        a_csw[j] = ((chunk ^ ((row >> 1) & 7)) << 4);
         const int m = m0 + row;
         if (m < p.M) {
             const int b = m / HoWo, rem = m - b * HoWo;
@@ -100,8 +106,13 @@ conv_igemm_kernel(const ConvKP p) {
         } else {
             a_b[j] = 0; a_iy[j] = -0x40000000; a_ix[j] = 0;      // always out of the image
         }
+    }
+#pragma unroll
+    for (int j = 0; j < BR; ++j) {
+        const int row = (wave * BR + j) * 8 + (lane >> 3);
+        b_csw[j] = ((chunk ^ ((row >> 1) & 7)) << 4);
         const int n = n0 + row;
-        b_src[j] = (n < p.Cout) ? p.w + ((size_t)n * p.K) * ESZ + csw[j] : nullptr;
+        b_src[j] = (n < p.Cout) ? p.w + ((size_t)n * p.K) * ESZ + b_csw[j] : nullptr;
     }
 
     // K-slab cursor (uniform): tap (r, s) and channel offset c0 inside the concatenated input
@@ -109,46 +120,50 @@ conv_igemm_kernel(const ConvKP p) {
     const int nk = p.K / BKE;
 
     auto stage = [&](int buf, int kt) {
-        char* la = smem + buf * 2 * TILE_BYTES;
-        char* lb = la + TILE_BYTES;
+        char* la = smem + buf * STAGE;
+        char* lb = la + A_BYTES;
         const bool first = c0 < p.C1;
         const char* src = first ? p.x1 : p.x2;
         const int cs = first ? p.C1 : p.C2;
         const int cc = first ? c0 : c0 - p.C1;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < AR; ++j) {
             const int iy = a_iy[j] + kr, ix = a_ix[j] + ks;
             const bool ok = (unsigned)iy < (unsigned)HL && (unsigned)ix < (unsigned)WL;
             const size_t pix = ((size_t)a_b[j] * p.H + (iy >> p.ups)) * p.W + (ix >> p.ups);
-            const char* s = ok ? src + (pix * cs + cc) * ESZ + csw[j] : p.zero + csw[j];
-            glds16(s, la + (wave * 4 + j) * 1024);
+            const char* s = ok ? src + (pix * cs + cc) * ESZ + a_csw[j] : p.zero + a_csw[j];
+            glds16(s, la + (wave * AR + j) * 1024);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const char* s = b_src[j] ? b_src[j] + (size_t)kt * SLAB : p.zero + csw[j];
-            glds16(s, lb + (wave * 4 + j) * 1024);
+        for (int j = 0; j < BR; ++j) {
+            const char* s = b_src[j] ? b_src[j] + (size_t)kt * SLAB : p.zero + b_csw[j];
+            glds16(s, lb + (wave * BR + j) * 1024);
         }
         c0 += BKE;
         if (c0 == Cin) { c0 = 0; if (++ks == p.R) { ks = 0; ++kr; } }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / NWN, wc = wave - wr * NWN;
     const int l31 = lane & 31, lh = lane >> 5;
     // fragment read offsets (bytes inside a tile) for k-step s: row*128 + ((2s+lh) ^ sw(row))*16
-    int a_off[2], b_off[2], a_sw[2], b_sw[2];
+    int a_off[TM], a_sw[TM], b_off[TN], b_sw[TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int ra = wr * 64 + i * 32 + l31, rb = wc * 64 + i * 32 + l31;
+    for (int i = 0; i < TM; ++i) {
+        const int ra = wr * WM + i * 32 + l31;
         a_off[i] = ra * SLAB; a_sw[i] = (ra >> 1) & 7;
-        b_off[i] = rb * SLAB; b_sw[i] = (rb >> 1) & 7;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int rb = wc * WN + j * 32 + l31;
+        b_off[j] = rb * SLAB; b_sw[j] = (rb >> 1) & 7;
     }
 
     stage(0, 0);
@@ -156,52 +171,127 @@ conv_igemm_kernel(const ConvKP p) {
         const int buf = kt & 1;
         if (kt + 1 < nk) {
             stage(buf ^ 1, kt + 1);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // slab kt landed, kt+1 in flight
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AR + BR) : "memory");   // slab kt landed, kt+1 in flight
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
-        const char* la = smem + buf * 2 * TILE_BYTES;
-        const char* lb = la + TILE_BYTES;
+        const char* la = smem + buf * STAGE;
+        const char* lb = la + A_BYTES;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            u32x4 af[2], bf[2];
+            u32x4 af[TM], bf[TN];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                af[i] = *(const u32x4*)(la + a_off[i] + ((((2 * s + lh) ^ a_sw[i])) << 4));
-                bf[i] = *(const u32x4*)(lb + b_off[i] + ((((2 * s + lh) ^ b_sw[i])) << 4));
-            }
+            for (int i = 0; i < TM; ++i) af[i] = *(const u32x4*)(la + a_off[i] + (((2 * s + lh) ^ a_sw[i]) << 4));
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < TN; ++j) bf[j] = *(const u32x4*)(lb + b_off[j] + (((2 * s + lh) ^ b_sw[j]) << 4));
 #pragma unroll
-                for (int j = 0; j < 2; ++j) Mma<T>::run(af[i], bf[j], acc[i][j]);
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) Mma<T>::run(af[i], bf[j], acc[i][j]);
         }
-        __builtin_amdgcn_s_barrier();                            // all reads of buf done before restage
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this wave's LDS reads retired ...
+        __builtin_amdgcn_s_barrier();                            // ... before anyone restages buf
     }
 
-    // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // ---- epilogue.  C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+    // Per 32-row strip the wave parks its 32 x WN accumulators in a private LDS patch
+    // (f32, row-major) and re-reads it one 16-byte output vector per lane.
+    constexpr int LPR = WN / VEC;                 // lanes per patch row
+    constexpr int RPI = 64 / LPR;                 // rows per wave-instruction
+    float* patch = (float*)smem + wave * (32 * WN);
     T* y = (T*)p.y;
     const T* res = (const T*)p.res;
+    const int prow = lane / LPR, pcv = lane - prow * LPR;
+    const int n = n0 + wc * WN + pcv * VEC;
+    const bool n_ok = n < p.Cout;                 // Cout is a multiple of VEC
+    float bias[VEC];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wc * 64 + j * 32 + l31;
-        if (n >= p.Cout) continue;
-        const float bias = p.bias ? p.bias[n] : 0.f;
+    for (int e = 0; e < VEC; ++e) bias[e] = (p.bias && n_ok) ? p.bias[n + e] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m >= p.M) continue;
-                float v = acc[i][j][r] + bias;
-                if (p.temb) v += p.temb[(size_t)(m / HoWo) * p.temb_stride + n];
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * WN + j * 32 + l31] = acc[i][j][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int it = 0; it < 32 / RPI; ++it) {
+            const int row = it * RPI + prow;
+            const int m = m0 + wr * WM + i * 32 + row;
+            float v[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; e += 4) {
+                const f32x4 t = *(const f32x4*)(patch + row * WN + pcv * VEC + e);
+                v[e] = t[0]; v[e + 1] = t[1]; v[e + 2] = t[2]; v[e + 3] = t[3];
+            }
+            if (m < p.M && n_ok) {
                 const size_t o = (size_t)m * p.Cout + n;
-                if (res) v += Elt<T>::ld(res + o);
-                Elt<T>::st(y + o, apply_act(v, p.act));
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v[e] += bias[e];
+                if (p.temb) {
+                    const float* tp = p.temb + (size_t)(m / HoWo) * p.temb_stride + n;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) v[e] += tp[e];
+                }
+                if (res) {
+                    float rv[VEC];
+                    unpack16<T>(*(const u32x4*)(res + o), rv);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) v[e] += rv[e];
+                }
+                if (p.act != ADVS_ACT_NONE) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) v[e] = apply_act(v[e], p.act);
+                }
+                *(u32x4*)(y + o) = pack16<T>(v);
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
+
+template <typename T, int BM, int BN, int WM, int WN>
+static int conv_launch(ConvKP& p, hipStream_t st) {
+    constexpr int NT = (BM / WM) * (BN / WN) * 64;
+    constexpr int lds = 2 * (BM + BN) * SLAB;
+    static bool attr_set = false;
+    if (!attr_set) {
+        ADVS_HIP(hipFuncSetAttribute((const void*)conv_igemm_kernel<T, BM, BN, WM, WN>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    p.nMt = cdiv(p.M, BM); p.nNt = cdiv(p.Cout, BN);
+    conv_igemm_kernel<T, BM, BN, WM, WN><<<p.nMt * p.nNt, NT, lds, st>>>(p);
+    ADVS_CHECK_LAUNCH("conv_igemm");
+    return ADVS_OK;
+}
+
+template <typename T>
+static int conv_dispatch(ConvKP& p, int tile, hipStream_t st) {
+    if (tile == 0) {
+        // measured on MI355X (tools/tune_conv.py, round 1): the 256x256 tile wins (~1.0-1.06 vs
+        // ~0.85 PFLOP/s) whenever Cout fills it and M still yields >= 1.5 blocks per CU; the
+        // 128x128 tile at two blocks per CU wins everywhere else, including Cout = 128.
+        const long long blocks256 = (long long)cdiv(p.M, 256) * cdiv(p.Cout, 256);
+        tile = (p.Cout % 256 == 0 && blocks256 >= 384) ? 4 : 1;
+    }
+    switch (tile) {
+        case 1: return conv_launch<T, 128, 128, 64, 64>(p, st);
+        case 2: return conv_launch<T, 256, 128, 64, 64>(p, st);
+        case 3: return conv_launch<T, 256, 128, 128, 64>(p, st);
+        case 4: return conv_launch<T, 256, 256, 128, 64>(p, st);
+        default: ADVS_FAIL(ADVS_ERR_ARG, "conv2d: unknown tile id %d", tile);
+    }
+}
+
+static int g_tile_override = 0;
+extern "C" int advs_conv_set_tile(int tile) { g_tile_override = tile; return ADVS_OK; }
 
 extern "C" int advs_conv2d(const advs_conv_args* a, void* stream) {
     ADVS_REQUIRE(a && a->x1 && a->w && a->y, "conv2d: null pointer");
@@ -214,6 +304,7 @@ extern "C" int advs_conv2d(const advs_conv_args* a, void* stream) {
     const int bke = SLAB / esz;
     ADVS_REQUIRE(a->c1 % bke == 0 && a->c2 % bke == 0, "conv2d: channels (%d,%d) must be multiples of %d",
                  a->c1, a->c2, bke);
+    ADVS_REQUIRE(a->cout % (16 / esz) == 0, "conv2d: cout=%d must be a multiple of %d", a->cout, 16 / esz);
     const void* zero = advs_zero_page();
     ADVS_REQUIRE(zero, "conv2d: advs_init() has not been called on this device");
     ConvKP p;
@@ -226,14 +317,11 @@ extern "C" int advs_conv2d(const advs_conv_args* a, void* stream) {
     p.Ho = (HL + 2 * a->pad - a->ksize) / a->stride + 1;
     p.Wo = (WL + 2 * a->pad - a->ksize) / a->stride + 1;
     const long long M = (long long)a->b * p.Ho * p.Wo;
-    ADVS_REQUIRE(M > 0 && M < (1ll << 31) - BM, "conv2d: M=%lld out of range", M);
+    ADVS_REQUIRE(M > 0 && M < (1ll << 31) - 256, "conv2d: M=%lld out of range", M);
     p.M = (int)M;
     p.K = a->ksize * a->ksize * (a->c1 + a->c2);
     p.act = a->act; p.temb_stride = a->temb_stride > 0 ? a->temb_stride : a->cout;
-    p.nMt = cdiv(M, BM); p.nNt = cdiv(a->cout, BN);
-    const int grid = p.nMt * p.nNt;
-    if (a->dtype == ADVS_BF16) conv_igemm_kernel<BF16><<<grid, NTHREADS, 0, (hipStream_t)stream>>>(p);
-    else conv_igemm_kernel<float><<<grid, NTHREADS, 0, (hipStream_t)stream>>>(p);
-    ADVS_CHECK_LAUNCH("conv_igemm");
-    return ADVS_OK;
+    const int tile = g_tile_override ? g_tile_override : a->tile;
+    if (a->dtype == ADVS_BF16) return conv_dispatch<BF16>(p, tile, (hipStream_t)stream);
+    return conv_dispatch<float>(p, tile, (hipStream_t)stream);
 }

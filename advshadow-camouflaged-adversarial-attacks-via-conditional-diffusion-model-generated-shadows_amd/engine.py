@@ -135,7 +135,7 @@ class Builder:
 
     # ---- ops (activations are NHWC tensors [B,H,W,C] of the compute dtype)
     def conv(self, x1, w, cout, *, x2=None, bias=None, temb=None, temb_stride=0, residual=None,
-             ksize=3, stride=1, pad=1, upsample=False, act=None, out=None):
+             ksize=3, stride=1, pad=1, upsample=False, act=None, out=None, tile=0):
         B, H, W, C1 = x1.shape
         C2 = 0 if x2 is None else x2.shape[3]
         HL, WL = (H * 2, W * 2) if upsample else (H, W)
@@ -144,7 +144,7 @@ class Builder:
         y = out if out is not None else self.buf((B, Ho, Wo, cout))
         a = ConvArgs(ptr(x1), ptr(x2), ptr(w), ptr(bias), ptr(temb), ptr(residual), ptr(y),
                      B, H, W, C1, C2, cout, ksize, stride, pad, 1 if upsample else 0,
-                     ACT[act], self.dt, temb_stride)
+                     ACT[act], self.dt, temb_stride, tile)
         self.plan.add(self.lib.advs_conv2d, C.byref(a), keep=(a, x1, x2, w, bias, temb, residual, y))
         return y
 

@@ -62,8 +62,10 @@ typedef struct advs_conv_args {
     int ksize, stride, pad, upsample;   /* ksize 1|3; upsample 0|1                          */
     int act, dtype;
     int temb_stride;                    /* floats between consecutive samples' temb rows    */
+    int tile;                           /* 0 = choose; 1: 128x128, 2|3: 256x128, 4: 256x256  */
 } advs_conv_args;
 int advs_conv2d(const advs_conv_args* a, void* stream);
+int advs_conv_set_tile(int tile);       /* tuning hook: non-zero overrides every call's tile  */
 
 /* First conv: NCHW f32 image (cin <= 4) -> NHWC `dtype`, 3x3 pad 1 (diff_model.py:192;
  * model/modules/conv.py:38 for inc).  w is the torch OIHW f32 weight.                      */

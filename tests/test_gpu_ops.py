@@ -41,9 +41,10 @@ CONV_CASES = [
 ]
 
 
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv2d(case, dt):
+def test_conv2d(case, dt, tile):
     B, H, W, C1, C2, Cout, k, stride, ups, has_b, has_t, has_r, act = case
     pad = 1 if k == 3 else 0
     x1 = rnd(B, C1, H, W, seed=1)
@@ -76,7 +77,7 @@ def test_conv2d(case, dt):
                   bias=bias.to(dev()) if has_b else None,
                   temb=tb[:, :Cout] if has_t else None, temb_stride=Cout + 5 if has_t else 0,
                   residual=nhwc(res, dt) if has_r else None,
-                  ksize=k, stride=stride, pad=pad, upsample=bool(ups), act=act)
+                  ksize=k, stride=stride, pad=pad, upsample=bool(ups), act=act, tile=tile)
     op.go()
     got = nchw(y)
     assert got.shape == ref.shape
