@@ -34,7 +34,10 @@ SIGNATURES = {
     "advs_conv_set_tile": [i32],
     "advs_conv3x3_first": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "advs_conv_last": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
-    "advs_groupnorm": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    "advs_groupnorm": [vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    "advs_maxpool2": [vp, vp, i32, i32, i32, i32, i32, vp],
+    "advs_concat_upsample2x": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "advs_layernorm": [vp, vp, vp, vp, C.c_longlong, i32, i32, vp],
     "advs_attention": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "advs_linear_f32": [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "advs_timestep_embedding": [vp, vp, i32, i32, vp, vp, vp, i32, vp],

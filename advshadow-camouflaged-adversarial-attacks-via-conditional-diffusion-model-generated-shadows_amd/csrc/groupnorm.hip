@@ -93,7 +93,8 @@ template <typename T>
 __global__ void __launch_bounds__(GN_THREADS)
 gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ x2, int C1, const float* __restrict__ gamma,
                 const float* __restrict__ beta, const T* __restrict__ res, T* __restrict__ y,
-                const float* __restrict__ partials, int HW, int C, int G, int nchunk, int nblk, int act) {
+                const float* __restrict__ partials, int HW, int C, int G, int nchunk, int nblk, int act,
+                const float* __restrict__ cadd, int cadd_stride) {
     constexpr int VEC = Elt<T>::VEC;
     __shared__ float s_mean[64], s_rstd[64];
     const int vpp = C / VEC, PIXB = GN_THREADS / vpp;
@@ -110,13 +111,14 @@ gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ x2, int C1, const
     __syncthreads();
     const int pl = tid / vpp, cv = tid - pl * vpp;
     if (pl >= PIXB) return;
-    float ca[VEC], cb[VEC];
+    float ca[VEC], cb[VEC], cc[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
         int c = cv * VEC + j, g = c / cpg;
         float a = s_rstd[g] * gamma[c];
         ca[j] = a;
         cb[j] = beta[c] - s_mean[g] * a;
+        cc[j] = cadd ? cadd[(size_t)b * cadd_stride + c] : 0.f;
     }
     const int per = (HW + nblk - 1) / nblk;
     const int p0 = blockIdx.x * per, p1 = min(HW, p0 + per);
@@ -136,7 +138,7 @@ gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ x2, int C1, const
         for (int j = 0; j < VEC; ++j) {
             float v = fmaf(f[j], ca[j], cb[j]);
             if (rb) v += r[j];
-            f[j] = apply_act(v, act);
+            f[j] = apply_act(v, act) + cc[j];
         }
         yb[(size_t)p * vpp] = pack16<T>(f);
     }
@@ -144,7 +146,8 @@ gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ x2, int C1, const
 
 template <typename T>
 static int gn_launch(const void* x, const void* x2, int c1, const float* gamma, const float* beta, const void* res,
-                     void* y, float* partials, int b, int hw, int c, int groups, int act, hipStream_t st) {
+                     void* y, float* partials, int b, int hw, int c, int groups, int act, const float* cadd,
+                     int cadd_stride, hipStream_t st) {
     constexpr int VEC = Elt<T>::VEC;
     const int vpp = c / VEC, PIXB = GN_THREADS / vpp;
     // enough chunks to fill 256 CUs several times over, but >= 4 pixels per lane per chunk
@@ -161,14 +164,16 @@ static int gn_launch(const void* x, const void* x2, int c1, const float* gamma, 
     if (nblk > maxb) nblk = maxb;
     if (nblk < 1) nblk = 1;
     gn_apply_kernel<T><<<dim3(nblk, b), GN_THREADS, 0, st>>>((const T*)x, (const T*)x2, c1, gamma, beta, (const T*)res,
-                                                             (T*)y, partials, hw, c, groups, nchunk, nblk, act);
+                                                             (T*)y, partials, hw, c, groups, nchunk, nblk, act,
+                                                             cadd, cadd_stride);
     ADVS_CHECK_LAUNCH("gn_apply");
     return ADVS_OK;
 }
 
 extern "C" int advs_groupnorm(const void* x, const void* x2, const float* gamma, const float* beta,
-                              const void* residual_in, void* y, void* partials, int b, int hw, int c1, int c2,
-                              int groups, int act, int dtype, void* stream) {
+                              const void* residual_in, const float* chan_add, int chan_add_stride, void* y,
+                              void* partials, int b, int hw, int c1, int c2, int groups, int act, int dtype,
+                              void* stream) {
     ADVS_REQUIRE(x && gamma && beta && y && partials, "groupnorm: null pointer");
     ADVS_REQUIRE(c1 > 0 && c2 >= 0 && (c2 == 0) == (x2 == nullptr), "groupnorm: x2/c2 mismatch");
     const int c = c1 + c2;
@@ -178,6 +183,8 @@ extern "C" int advs_groupnorm(const void* x, const void* x2, const float* gamma,
     ADVS_REQUIRE(c1 % vec == 0 && c2 % vec == 0 && c / vec <= GN_THREADS, "groupnorm: c=%d+%d unsupported for dtype %d", c1, c2, dtype);
     ADVS_REQUIRE((size_t)(GN_THREADS / (c / vec)) * c * 8 <= 65536, "groupnorm: LDS budget exceeded for c=%d", c);
     if (dtype == ADVS_BF16)
-        return gn_launch<BF16>(x, x2, c1, gamma, beta, residual_in, y, (float*)partials, b, hw, c, groups, act, (hipStream_t)stream);
-    return gn_launch<float>(x, x2, c1, gamma, beta, residual_in, y, (float*)partials, b, hw, c, groups, act, (hipStream_t)stream);
+        return gn_launch<BF16>(x, x2, c1, gamma, beta, residual_in, y, (float*)partials, b, hw, c, groups, act,
+                               chan_add, chan_add_stride, (hipStream_t)stream);
+    return gn_launch<float>(x, x2, c1, gamma, beta, residual_in, y, (float*)partials, b, hw, c, groups, act,
+                            chan_add, chan_add_stride, (hipStream_t)stream);
 }

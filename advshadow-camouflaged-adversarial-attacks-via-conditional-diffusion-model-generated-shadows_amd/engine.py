@@ -161,13 +161,34 @@ class Builder:
                       keep=(x, w, bias, out_nchw))
         return out_nchw
 
-    def groupnorm(self, x, gamma, beta, groups, act=None, x2=None, residual=None):
+    def groupnorm(self, x, gamma, beta, groups, act=None, x2=None, residual=None, chan_add=None, chan_add_stride=0):
         B, H, W, C1 = x.shape
         C2 = 0 if x2 is None else x2.shape[3]
         y = self.buf((B, H, W, C1 + C2))
-        self.plan.add(self.lib.advs_groupnorm, ptr(x), ptr(x2), ptr(gamma), ptr(beta), ptr(residual), ptr(y),
-                      ptr(self.gn_scratch), B, H * W, C1, C2, groups, ACT[act], self.dt,
-                      keep=(x, x2, gamma, beta, residual, y))
+        self.plan.add(self.lib.advs_groupnorm, ptr(x), ptr(x2), ptr(gamma), ptr(beta), ptr(residual), ptr(chan_add),
+                      chan_add_stride, ptr(y), ptr(self.gn_scratch), B, H * W, C1, C2, groups, ACT[act], self.dt,
+                      keep=(x, x2, gamma, beta, residual, chan_add, y))
+        return y
+
+    def maxpool2(self, x):
+        B, H, W, Cc = x.shape
+        y = self.buf((B, H // 2, W // 2, Cc))
+        self.plan.add(self.lib.advs_maxpool2, ptr(x), ptr(y), B, H, W, Cc, self.dt, keep=(x, y))
+        return y
+
+    def concat_upsample2x(self, skip, x):
+        B, h, w, C2 = x.shape
+        C1 = skip.shape[3]
+        y = self.buf((B, 2 * h, 2 * w, C1 + C2))
+        self.plan.add(self.lib.advs_concat_upsample2x, ptr(skip), ptr(x), ptr(y), B, h, w, C1, C2, self.dt,
+                      keep=(skip, x, y))
+        return y
+
+    def layernorm(self, x, gamma, beta):
+        rows = x.numel() // x.shape[-1]
+        y = self.buf(tuple(x.shape))
+        self.plan.add(self.lib.advs_layernorm, ptr(x), ptr(gamma), ptr(beta), ptr(y), rows, x.shape[-1], self.dt,
+                      keep=(x, gamma, beta, y))
         return y
 
     def attention(self, qkv, heads, d, q_off, k_off, v_off, head_stride):

@@ -84,9 +84,23 @@ int advs_conv_last(const void* x, const float* w_oihw, const float* bias, float*
 size_t advs_groupnorm_scratch_bytes(int b, int groups);
 /* x2/c2: optional second source concatenated after x on the channel axis (the norm of
  * torch.cat([h, skip]), diff_model.py:265 -> :71); y is the concatenated [b][hw][c+c2].     */
+/* chan_add (or NULL): per-sample per-channel vector added AFTER the activation,
+ * y += chan_add[b*chan_add_stride + c]  (x + emb_layer(t)[:, :, None, None], block.py:47-49). */
 int advs_groupnorm(const void* x, const void* x2, const float* gamma, const float* beta,
-                   const void* residual_in, void* y, void* partials, int b, int hw, int c, int c2,
-                   int groups, int act, int dtype, void* stream);
+                   const void* residual_in, const float* chan_add, int chan_add_stride, void* y,
+                   void* partials, int b, int hw, int c, int c2, int groups, int act, int dtype,
+                   void* stream);
+
+/* ---- resampling / token norm of the class-conditional UNet -----------------------------
+ * MaxPool2d(2) (model/modules/block.py:27); y is [b][h/2][w/2][c].                          */
+int advs_maxpool2(const void* x, void* y, int b, int h, int w, int c, int dtype, void* stream);
+/* y = cat([skip, Upsample(scale 2, bilinear, align_corners=True)(x)], channel axis)
+ * (block.py:66,86-87): skip [b][2h][2w][c1], x [b][h][w][c2] -> y [b][2h][2w][c1+c2].          */
+int advs_concat_upsample2x(const void* skip, const void* x, void* y, int b, int h, int w, int c1, int c2,
+                           int dtype, void* stream);
+/* nn.LayerNorm([c]) over the last axis of [rows][c], eps 1e-5 (model/modules/attention.py:25,27). */
+int advs_layernorm(const void* x, const float* gamma, const float* beta, void* y, long long rows, int c,
+                   int dtype, void* stream);
 
 /* ---- self-attention, flash style -------------------------------------------------------
  * softmax(q k^T / sqrt(d)) v per (batch, head) without materialising the N x N scores

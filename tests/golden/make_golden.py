@@ -97,7 +97,49 @@ def gen_lineage_b():
     run("default", 0, {}, 64, 1, [1, 501, 981], 10)
 
 
-GROUPS = {"lineage_b": gen_lineage_b}
+# --------------------------------------------------------------------------- lineage A
+def gen_lineage_a():
+    from model.networks.unet import UNet
+    from model.samples.ddim import DDIMDiffusion
+    import model.samples.ddim as ddim_mod
+    ddim_mod.tqdm = lambda it, **k: it
+
+    def run(tag, seed, act, with_sample):
+        torch.manual_seed(seed)
+        net = UNet(num_classes=37, device="cpu", image_size=64, act=act).eval()
+        keys, dg = digest(net.state_dict())
+        g = torch.Generator().manual_seed(2000 + seed)
+        x = torch.randn(2, 3, 64, 64, generator=g)
+        t = torch.tensor([31, 901])
+        y = torch.tensor([17, 3])
+        arrs = dict(sd_keys=keys, sd_digest=dg, x=x.numpy(), t=t.numpy(), y=y.numpy())
+        with torch.no_grad():
+            arrs["eps_cond"] = net(x, t, y).numpy()
+            arrs["eps_uncond"] = net(x, t).numpy()
+        if with_sample:
+            diff = DDIMDiffusion(sample_steps=10, img_size=64, device="cpu")
+            arrs["alpha_hat"] = diff.alpha_hat.numpy()
+            arrs["time_pairs"] = np.array([[int(a), int(b)] for a, b in diff.time_step])
+            labels = torch.tensor([5, 30])
+            torch.manual_seed(4321)
+            xT = torch.randn((2, 3, 64, 64))                       # first draw of sample() (ddim.py:62)
+            torch.manual_seed(4321)
+            arrs["sample_xT"] = xT.numpy()
+            arrs["sample_labels"] = labels.numpy()
+            arrs["sample_cfg3"] = diff.sample(net, 2, labels=labels, cfg_scale=3).numpy()
+            torch.manual_seed(4321)
+            arrs["sample_uncond"] = diff.sample(net, 2).numpy()
+            net.eval()
+        save(f"lineage_a_{tag}.npz", **arrs)
+
+    run("silu", 1, "silu", True)
+    run("gelu", 2, "gelu", False)
+    d500 = DDIMDiffusion(img_size=64, device="cpu")                # defaults: 500 sample steps
+    save("lineage_a_schedule.npz", alpha_hat=d500.alpha_hat.numpy(),
+         time_pairs_500=np.array([[int(a), int(b)] for a, b in d500.time_step]))
+
+
+GROUPS = {"lineage_b": gen_lineage_b, "lineage_a": gen_lineage_a}
 
 if __name__ == "__main__":
     for g in (sys.argv[1:] or list(GROUPS)):

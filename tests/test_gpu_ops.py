@@ -290,3 +290,59 @@ def test_layout_roundtrip(dt):
     ref = bf16_round(x) if dt == "bf16" else x
     assert torch.equal(y.float().cpu(), ref.permute(0, 2, 3, 1).contiguous())
     assert torch.equal(z.cpu(), ref)
+
+
+# ------------------------------------------------------------------------------ lineage-A resampling ops
+@pytest.mark.parametrize("dt", DTS)
+def test_maxpool2(dt):
+    x = rnd(2, 64, 12, 16, seed=21)
+    xr = bf16_round(x) if dt == "bf16" else x
+    op = OneOp(dt, 2)
+    y = op.b.maxpool2(nhwc(x, dt))
+    op.go()
+    assert torch.equal(nchw(y), F.max_pool2d(xr, 2))
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("shape", [(2, 8, 8, 64, 128), (1, 4, 6, 128, 64), (1, 1, 1, 64, 64)])
+def test_concat_upsample2x(shape, dt):
+    B, h, w, C1, C2 = shape
+    skip, x = rnd(B, C1, 2 * h, 2 * w, seed=22), rnd(B, C2, h, w, seed=23)
+    if dt == "bf16":
+        skip, x = bf16_round(skip), bf16_round(x)
+    ref = torch.cat([skip, F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)], 1)
+    op = OneOp(dt, B)
+    y = op.b.concat_upsample2x(nhwc(skip, dt), nhwc(x, dt))
+    op.go()
+    err = (nchw(y) - ref).abs().max().item()
+    assert err < tol(dt, 2e-6, 2e-2), err
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64), (1, 8, 8, 256), (3, 5, 7, 128)])
+def test_layernorm(shape, dt):
+    B, H, W, Cc = shape
+    x = rnd(B, H, W, Cc, seed=24) * 3 + 1
+    g, b = rnd(Cc, seed=25) + 1, rnd(Cc, seed=26)
+    xr = bf16_round(x) if dt == "bf16" else x
+    ref = F.layer_norm(xr, (Cc,), g, b, eps=1e-5)
+    op = OneOp(dt, B)
+    y = op.b.layernorm(x.to(dev(), torch.bfloat16 if dt == "bf16" else torch.float32), g.to(dev()), b.to(dev()))
+    op.go()
+    err = (y.float().cpu() - ref).abs().max().item()
+    assert err < tol(dt, 1e-5, 4e-2), err
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_groupnorm_chan_add(dt):
+    B, C, H, W = 2, 128, 8, 8
+    x, emb = rnd(B, C, H, W, seed=27), rnd(B, C + 64, seed=28)
+    g, b = rnd(C, seed=29) + 1, rnd(C, seed=30)
+    xr = bf16_round(x) if dt == "bf16" else x
+    ref = F.group_norm(xr, 1, g, b, eps=1e-5) + emb[:, 32:32 + C, None, None]
+    op = OneOp(dt, B)
+    e = emb.to(dev())
+    y = op.b.groupnorm(nhwc(x, dt), g.to(dev()), b.to(dev()), 1, chan_add=e[:, 32:32 + C], chan_add_stride=C + 64)
+    op.go()
+    err = (nchw(y) - ref).abs().max().item()
+    assert err < tol(dt, 2e-5, 3e-2), err

@@ -1,0 +1,57 @@
+"""The CPU oracle vs golden vectors of the imported reference (model/networks/unet.py, model/samples/ddim.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import lineage_a as oa
+
+CASES = {"silu": (1, "silu"), "gelu": (2, "gelu")}
+
+
+def wrap_diff(a, b):
+    """uint8 distance modulo 256 (the reference's cast wraps, ddim.py:97-99)."""
+    d = (a.astype(np.int16) - b.astype(np.int16)) % 256
+    return np.minimum(d, 256 - d)
+
+
+def test_schedule_and_pairs(golden):
+    g = golden("lineage_a_schedule.npz")
+    assert np.array_equal(oa.alpha_hat().numpy(), g["alpha_hat"])            # float32, bit-exact
+    assert [list(p) for p in oa.time_pairs(1000, 500)] == g["time_pairs_500"].tolist()
+    s = golden("lineage_a_silu.npz")
+    assert [list(p) for p in oa.time_pairs(1000, 10)] == s["time_pairs"].tolist()
+    assert oa.time_pairs(1000, 10)[0] == (901, 801) and oa.time_pairs(1000, 10)[-1] == (1, 0)
+
+
+@pytest.mark.parametrize("tag", list(CASES))
+def test_seeded_init_matches_reference(golden, tag):
+    seed, act = CASES[tag]
+    g = golden(f"lineage_a_{tag}.npz")
+    sd = oa.init_state_dict(seed, num_classes=37, act=act)
+    keys = list(g["sd_keys"])
+    assert sorted(sd.keys()) == keys
+    mine = np.array([[float(sd[k].double().sum()), float(sd[k].double().abs().sum())] for k in keys])
+    assert np.array_equal(mine, g["sd_digest"])
+
+
+@pytest.mark.parametrize("tag", list(CASES))
+def test_forward_matches_reference(golden, tag):
+    seed, act = CASES[tag]
+    g = golden(f"lineage_a_{tag}.npz")
+    sd = oa.init_state_dict(seed, num_classes=37, act=act)
+    x, t, y = torch.from_numpy(g["x"]), torch.from_numpy(g["t"]), torch.from_numpy(g["y"])
+    assert np.abs(oa.unet_forward(sd, x, t, y, act=act).numpy() - g["eps_cond"]).max() < 2e-5
+    assert np.abs(oa.unet_forward(sd, x, t, None, act=act).numpy() - g["eps_uncond"]).max() < 2e-5
+
+
+def test_ddim_sample_matches_reference(golden):
+    g = golden("lineage_a_silu.npz")
+    sd = oa.init_state_dict(1, num_classes=37, act="silu")
+    fn = lambda x, t, y: oa.unet_forward(sd, x, t, y)
+    xT = torch.from_numpy(g["sample_xT"])
+    out = oa.ddim_sample(fn, xT, labels=torch.from_numpy(g["sample_labels"]), cfg_scale=3, sample_steps=10).numpy()
+    d = wrap_diff(out, g["sample_cfg3"])
+    assert out.dtype == np.uint8 and d.max() <= 1 and (d > 0).mean() < 0.01
+    out = oa.ddim_sample(fn, xT, sample_steps=10).numpy()
+    d = wrap_diff(out, g["sample_uncond"])
+    assert d.max() <= 1 and (d > 0).mean() < 0.01
