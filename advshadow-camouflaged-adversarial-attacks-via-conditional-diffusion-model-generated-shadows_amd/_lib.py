@@ -43,6 +43,13 @@ SIGNATURES = {
     "advs_timestep_embedding": [vp, vp, i32, i32, vp, vp, vp, i32, vp],
     "advs_ddim_step": [vp, vp, vp, f32, vp, vp, vp, i32, vp, vp, i32, sz, i32, vp],
     "advs_to_uint8": [vp, vp, sz, i32, vp],
+    "advs_apply_shadow": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, C.POINTER(f32), i32, vp],
+    "advs_composite_u8": [vp, vp, vp, vp, sz, i32, f32, vp],
+    "advs_resample_u8": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "advs_u8hwc_to_f32nchw": [vp, vp, i32, i32, i32, i32, vp, vp, vp],
+    "advs_u8_nchw_to_hwc": [vp, vp, i32, i32, i32, i32, vp],
+    "advs_psnr_ssim": [vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "advs_argmax_rows": [vp, vp, i32, i32, vp],
     "advs_graph_begin": [vp],
     "advs_graph_end": [vp, C.POINTER(vp)],
     "advs_graph_launch": [vp, vp],

@@ -140,6 +140,37 @@ int advs_ddim_step(float* x, const float* eps, const float* eps_uncond, float cf
  * or clamped when clamp != 0.                                                                */
 int advs_to_uint8(const float* x, uint8_t* y, size_t n, int clamp, void* stream);
 
+/* ---- shadow composite, image hand-off, metrics ------------------------------------------------
+ * Closed form of apply_shadow (tools/train_shadow.py:242-256,262-266; ddim2/test.py:830-871; with
+ * ntaps = 1, taps = {1}: ddim2/diff_model2.py:615-654): circular mask at centers[b] = (cx, cy) with
+ * radii[b], blurred by the separable `taps` (cv2.GaussianBlur(k, sigma 0), BORDER_REFLECT_101),
+ * times feature_mask; img/out NCHW f32 [b][c][h][w], feature_mask [b][mask_channels][h][w].     */
+int advs_apply_shadow(const float* img, const float* feature_mask, const float* centers, const float* radii,
+                      float* out, int b, int c, int h, int w, int mask_channels, float intensity,
+                      const float* taps, int ntaps, void* stream);
+/* Pillow-exact uint8 composites on [npix] RGB pixels with an RGBA layer and an L mask.
+ * mode 0: Image.composite(Image.alpha_composite(img, layer), img, mask)      (add_shadow.py:57-58)
+ * mode 1: add_shadow_to_mask_area + adjust_shadow_brightness(factor)  (shadow_for_attack.py:50-93) */
+int advs_composite_u8(const uint8_t* img_hwc, const uint8_t* layer_rgba, const uint8_t* mask,
+                      uint8_t* out_hwc, size_t npix, int mode, float factor, void* stream);
+/* One pass of Pillow's 8-bit ImagingResample (Image.resize behind transforms.Resize, ASR_fast.py:93,
+ * PSNR_SSIM_fast.py:11): bounds[o] = {first input index, tap count}, coefs[o][ksize] int32 fixed
+ * point (22 bits), computed by the host as Pillow does.  Images [n][h][w][channels] uint8.        */
+int advs_resample_u8(const uint8_t* in, uint8_t* out, const int* bounds, const int* coefs, int ksize,
+                     int n, int in_h, int in_w, int out_h, int out_w, int channels, int horizontal,
+                     void* stream);
+/* transforms.ToTensor (+ optional Normalize): uint8 [n][h][w][ch] -> f32 [n][ch][h][w] / 255.        */
+int advs_u8hwc_to_f32nchw(const uint8_t* in, float* out, int n, int h, int w, int channels,
+                          const float* mean, const float* stdv, void* stream);
+/* uint8 [n][ch][h][w] -> [n][h][w][ch]: the permute of save_images (utils/utils.py:59-60).           */
+int advs_u8_nchw_to_hwc(const uint8_t* in, uint8_t* out, int n, int channels, int h, int w, void* stream);
+/* calculate_ssim_psnr (PSNR_SSIM_fast.py:21-26, skimage semantics) for b image pairs, NCHW f32,
+ * planes <= 64x64: out[b] = {ssim, psnr} as f64.                                                 */
+int advs_psnr_ssim(const float* img1, const float* img2, double* out_ssim_psnr, int b, int c, int h, int w,
+                   int win_size, void* stream);
+/* torch.max(outputs, 1) indices (ASR_fast.py:115): first maximum of each row.                      */
+int advs_argmax_rows(const float* x, int* out, int rows, int n, void* stream);
+
 /* ---- stream capture (hipGraph) -------------------------------------------------------- */
 int advs_graph_begin(void* stream);
 int advs_graph_end(void* stream, void** graph_exec_out);
