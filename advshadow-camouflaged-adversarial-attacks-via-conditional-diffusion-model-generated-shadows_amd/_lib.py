@@ -50,6 +50,9 @@ SIGNATURES = {
     "advs_u8_nchw_to_hwc": [vp, vp, i32, i32, i32, i32, vp],
     "advs_psnr_ssim": [vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "advs_argmax_rows": [vp, vp, i32, i32, vp],
+    "advs_conv_stem": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "advs_maxpool3x3s2": [vp, vp, i32, i32, i32, i32, i32, vp],
+    "advs_global_avgpool": [vp, vp, i32, i32, i32, i32, vp],
     "advs_graph_begin": [vp],
     "advs_graph_end": [vp, C.POINTER(vp)],
     "advs_graph_launch": [vp, vp],

@@ -74,11 +74,12 @@ extern "C" int advs_apply_shadow(const float* img, const float* feature_mask, co
 }
 
 // ============================================================================ PIL composites (uint8)
-// Pillow fixed point: MULDIV255(a,b) = t=a*b+128, ((t>>8)+t)>>8 ; SHIFTFORDIV255(a) = ((a>>8)+a)>>8.
-__device__ __forceinline__ unsigned muldiv255(unsigned a, unsigned b) { unsigned t = a * b + 128; return ((t >> 8) + t) >> 8; }
+// Pillow fixed point: SHIFTFORDIV255(a) = ((a>>8)+a)>>8.
 __device__ __forceinline__ unsigned shiftdiv255(unsigned a) { return ((a >> 8) + a) >> 8; }
-__device__ __forceinline__ unsigned blend8(unsigned mask, unsigned in1, unsigned in2) {   // Paste.c BLEND8
-    return muldiv255(in1, 255 - mask) + muldiv255(in2, mask);
+// Paste.c BLEND8 as Pillow >= 10 computes it (one rounding): DIV255(in1*(255-mask) + in2*mask).
+// Checked against the installed Pillow 12.2 by tests/test_gpu_shadow_metrics.py.
+__device__ __forceinline__ unsigned blend8(unsigned mask, unsigned in1, unsigned in2) {
+    return shiftdiv255(in1 * (255u - mask) + in2 * mask + 128u);
 }
 // Image.alpha_composite(dst (opaque RGB), src RGBA) -> RGB  (libImaging/AlphaComposite.c, dst alpha 255)
 __device__ __forceinline__ void alpha_composite_px(const unsigned* dst, const unsigned* src, unsigned* out) {

@@ -1,0 +1,146 @@
+// Victim-classifier pieces that are not GEMM-shaped (ResNet-50 of ASR_fast.py:16-20 /
+// ddim2/diff_model2.py:19-44): the 7x7 stride-2 stem on the 3-channel image, MaxPool2d(3,2,1) and
+// the global average pool.  Everything else in the network is advs_conv2d (BatchNorm folded into
+// the packed weights by the host, ReLU / residual in the epilogue) and advs_linear_f32.
+#include "common.h"
+
+// ---------------------------------------------------------------- stem: NCHW f32 -> NHWC T
+// y = act(conv(x, w[cout][cin][k][k], stride, pad) + bias).  thread = one output pixel x cout/4
+// channels; weights broadcast from LDS.
+template <typename T>
+__global__ void __launch_bounds__(256)
+conv_stem_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                 T* __restrict__ y, int B, int Cin, int H, int W, int Cout, int K, int stride, int pad,
+                 int Ho, int Wo, int act) {
+    extern __shared__ float sw[];                 // [cin*k*k][cout] then bias
+    const int KK = Cin * K * K;
+    for (int i = threadIdx.x; i < KK * Cout; i += 256) {
+        const int k = i / Cout, o = i - k * Cout;
+        sw[i] = w[(size_t)o * KK + k];
+    }
+    for (int i = threadIdx.x; i < Cout; i += 256) sw[KK * Cout + i] = bias ? bias[i] : 0.f;
+    __syncthreads();
+    const int px = threadIdx.x & 63, cq = threadIdx.x >> 6, cper = Cout / 4;
+    const long long npix = (long long)B * Ho * Wo;
+    for (long long pb = (long long)blockIdx.x * 64; pb < npix; pb += (long long)gridDim.x * 64) {
+        const long long pix = pb + px;
+        if (pix >= npix) continue;
+        const int b = (int)(pix / (Ho * Wo)), rem = (int)(pix - (long long)b * Ho * Wo);
+        const int oy = rem / Wo, ox = rem - oy * Wo;
+        T* yo = y + (size_t)pix * Cout + cq * cper;
+        for (int c8 = 0; c8 < cper; c8 += 8) {
+            float acc[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = sw[KK * Cout + cq * cper + c8 + j];
+            for (int c = 0; c < Cin; ++c)
+                for (int r = 0; r < K; ++r) {
+                    const int iy = oy * stride + r - pad;
+                    if ((unsigned)iy >= (unsigned)H) continue;
+                    const float* xr = x + (((size_t)b * Cin + c) * H + iy) * W;
+                    for (int s = 0; s < K; ++s) {
+                        const int ix = ox * stride + s - pad;
+                        if ((unsigned)ix >= (unsigned)W) continue;
+                        const float v = xr[ix];
+                        const float* wr = sw + ((c * K + r) * K + s) * Cout + cq * cper + c8;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[j] = fmaf(v, wr[j], acc[j]);
+                    }
+                }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = apply_act(acc[j], act);
+            *(u32x4*)(yo + c8) = pack16<T>(acc);
+            if (sizeof(T) == 4) *(u32x4*)(yo + c8 + 4) = pack16<T>(acc + 4);
+        }
+    }
+}
+
+extern "C" int advs_conv_stem(const float* x_nchw, const float* w_oihw, const float* bias, void* y,
+                              int b, int cin, int h, int w, int cout, int ksize, int stride, int pad, int act,
+                              int dtype, void* stream) {
+    ADVS_REQUIRE(x_nchw && w_oihw && y && b > 0 && h > 0 && w > 0, "conv_stem: bad args");
+    ADVS_REQUIRE(cin >= 1 && cin <= 4 && cout % 32 == 0 && ksize >= 1 && ksize <= 7 && stride >= 1 && pad >= 0,
+                 "conv_stem: unsupported shape cin=%d cout=%d k=%d", cin, cout, ksize);
+    const size_t lds = ((size_t)cin * ksize * ksize * cout + cout) * sizeof(float);
+    ADVS_REQUIRE(lds <= 65536, "conv_stem: weights do not fit LDS");
+    const int ho = (h + 2 * pad - ksize) / stride + 1, wo = (w + 2 * pad - ksize) / stride + 1;
+    const long long npix = (long long)b * ho * wo;
+    const int grid = (int)((npix + 63) / 64 < 8192 ? (npix + 63) / 64 : 8192);
+    if (dtype == ADVS_BF16)
+        conv_stem_kernel<BF16><<<grid, 256, lds, (hipStream_t)stream>>>(x_nchw, w_oihw, bias, (BF16*)y, b, cin, h, w, cout,
+                                                                        ksize, stride, pad, ho, wo, act);
+    else
+        conv_stem_kernel<float><<<grid, 256, lds, (hipStream_t)stream>>>(x_nchw, w_oihw, bias, (float*)y, b, cin, h, w, cout,
+                                                                         ksize, stride, pad, ho, wo, act);
+    ADVS_CHECK_LAUNCH("conv_stem");
+    return ADVS_OK;
+}
+
+// ---------------------------------------------------------------- MaxPool2d(3, stride 2, pad 1), NHWC
+template <typename T>
+__global__ void maxpool3s2_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, int Ho, int Wo) {
+    constexpr int VEC = Elt<T>::VEC;
+    const int vpp = C / VEC;
+    const size_t total = (size_t)B * Ho * Wo * vpp;
+    const u32x4* xv = (const u32x4*)x;
+    u32x4* yv = (u32x4*)y;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % vpp);
+        size_t r = i / vpp;
+        const int ox = (int)(r % Wo); r /= Wo;
+        const int oy = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        float m[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) m[j] = -INFINITY;
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int iy = 2 * oy + dy;
+            if ((unsigned)iy >= (unsigned)H) continue;
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int ix = 2 * ox + dx;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                float t[VEC];
+                unpack16<T>(xv[(((size_t)b * H + iy) * W + ix) * vpp + cv], t);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) m[j] = fmaxf(m[j], t[j]);
+            }
+        }
+        yv[i] = pack16<T>(m);
+    }
+}
+
+extern "C" int advs_maxpool3x3s2(const void* x, void* y, int b, int h, int w, int c, int dtype, void* stream) {
+    ADVS_REQUIRE(x && y && b > 0 && h > 0 && w > 0, "maxpool3x3s2: bad args");
+    const int vec = dtype == ADVS_BF16 ? 8 : 4;
+    ADVS_REQUIRE(c % vec == 0, "maxpool3x3s2: c=%d must be a multiple of %d", c, vec);
+    const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+    const size_t total = (size_t)b * ho * wo * (c / vec);
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    if (dtype == ADVS_BF16) maxpool3s2_kernel<BF16><<<grid, 256, 0, (hipStream_t)stream>>>((const BF16*)x, (BF16*)y, b, h, w, c, ho, wo);
+    else maxpool3s2_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>((const float*)x, (float*)y, b, h, w, c, ho, wo);
+    ADVS_CHECK_LAUNCH("maxpool3x3s2");
+    return ADVS_OK;
+}
+
+// ---------------------------------------------------------------- AdaptiveAvgPool2d(1): NHWC T -> f32 [B][C]
+template <typename T>
+__global__ void __launch_bounds__(256)
+global_avgpool_kernel(const T* __restrict__ x, float* __restrict__ y, int HW, int C) {
+    __shared__ float part[256];
+    const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < C)
+        for (int p = q; p < HW; p += 4) s += Elt<T>::ld(x + ((size_t)b * HW + p) * C + c);
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (q == 0 && c < C)
+        y[(size_t)b * C + c] = (part[threadIdx.x] + part[threadIdx.x + 64] + part[threadIdx.x + 128] + part[threadIdx.x + 192]) / (float)HW;
+}
+
+extern "C" int advs_global_avgpool(const void* x, float* y, int b, int hw, int c, int dtype, void* stream) {
+    ADVS_REQUIRE(x && y && b > 0 && hw > 0 && c > 0, "global_avgpool: bad args");
+    dim3 grid(cdiv(c, 64), b);
+    if (dtype == ADVS_BF16) global_avgpool_kernel<BF16><<<grid, 256, 0, (hipStream_t)stream>>>((const BF16*)x, y, hw, c);
+    else global_avgpool_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>((const float*)x, y, hw, c);
+    ADVS_CHECK_LAUNCH("global_avgpool");
+    return ADVS_OK;
+}

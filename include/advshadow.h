@@ -171,6 +171,16 @@ int advs_psnr_ssim(const float* img1, const float* img2, double* out_ssim_psnr, 
 /* torch.max(outputs, 1) indices (ASR_fast.py:115): first maximum of each row.                      */
 int advs_argmax_rows(const float* x, int* out, int rows, int n, void* stream);
 
+/* ---- victim classifier pieces that are not GEMMs ---------------------------------------------
+ * (timm/torchvision ResNet-50: ASR_fast.py:16-20, ddim2/diff_model2.py:19-44; BatchNorm is folded
+ * into weights+bias by the host, eval mode).  Stem: NCHW f32 image -> NHWC `dtype`,
+ * y = act(conv_{k x k, stride, pad}(x) + bias), cin <= 4, w in torch OIHW f32.                    */
+int advs_conv_stem(const float* x_nchw, const float* w_oihw, const float* bias, void* y,
+                   int b, int cin, int h, int w, int cout, int ksize, int stride, int pad, int act,
+                   int dtype, void* stream);
+int advs_maxpool3x3s2(const void* x, void* y, int b, int h, int w, int c, int dtype, void* stream); /* MaxPool2d(3,2,1) */
+int advs_global_avgpool(const void* x, float* y, int b, int hw, int c, int dtype, void* stream);    /* -> f32 [b][c] */
+
 /* ---- stream capture (hipGraph) -------------------------------------------------------- */
 int advs_graph_begin(void* stream);
 int advs_graph_end(void* stream, void** graph_exec_out);

@@ -1,0 +1,105 @@
+"""Victim forward, ASR evaluation and conv-stem / pooling kernels on the MI355X vs the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+from PIL import Image
+
+pytestmark = pytest.mark.gpu
+
+from gpu_helpers import OneOp, bf16_round, dev, nchw, nhwc  # noqa: E402
+from advshadow_amd import _lib, asr  # noqa: E402
+from advshadow_amd.engine import ptr  # noqa: E402
+from advshadow_amd.victims import ResNet50  # noqa: E402
+from oracle import victims as ov  # noqa: E402
+
+
+def make_victim(seed=1, **kw):
+    torch.manual_seed(seed)
+    net = ResNet50(num_classes=37, **kw)
+    sd = ov.randomize_bn({k: v.clone() for k, v in net.state_dict().items()}, seed + 100)
+    net.load_state_dict(sd)
+    return net.to("cuda").eval(), {k: v.cpu() for k, v in sd.items()}
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_stem_pool_avg_kernels(dt):
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(2, 3, 37, 41, generator=g)
+    w, b = torch.randn(64, 3, 7, 7, generator=g) * 0.05, torch.randn(64, generator=g) * 0.1
+    ref = F.relu(F.conv2d(x, w, b, stride=2, padding=3))
+    op = OneOp(dt, 2)
+    lib = op.b.lib
+    xd, wd, bd = x.to(dev()), w.to(dev()), b.to(dev())
+    y = op.b.buf((2, ref.shape[2], ref.shape[3], 64))
+    op.b.plan.add(lib.advs_conv_stem, ptr(xd), ptr(wd), ptr(bd), ptr(y), 2, 3, 37, 41, 64, 7, 2, 3, _lib.ACT["relu"], op.b.dt)
+    refp = F.max_pool2d(bf16_round(ref) if dt == "bf16" else ref, 3, 2, 1)
+    yp = op.b.buf((2, refp.shape[2], refp.shape[3], 64))
+    op.b.plan.add(lib.advs_maxpool3x3s2, ptr(y), ptr(yp), 2, ref.shape[2], ref.shape[3], 64, op.b.dt)
+    ya = torch.empty(2, 64, device=dev())
+    op.b.plan.add(lib.advs_global_avgpool, ptr(yp), ptr(ya), 2, refp.shape[2] * refp.shape[3], 64, op.b.dt)
+    op.go()
+    tol = 1e-5 if dt == "fp32" else 3e-2
+    assert (nchw(y) - ref).abs().max().item() < tol
+    assert (nchw(yp) - refp).abs().max().item() < tol
+    assert (ya.cpu() - refp.mean((2, 3))).abs().max().item() < tol
+
+
+def test_resnet50_fp32_matches_oracle_and_top1():
+    net, sd = make_victim()
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(4, 3, 224, 224, generator=g)
+    ref = ov.resnet50_forward(sd, x)
+    for _ in range(2):
+        got = net(x.cuda()).cpu()
+        assert (got - ref).abs().max().item() < 2e-3 * ref.abs().max().item()
+        assert torch.equal(got.argmax(1), ref.argmax(1))
+
+
+def test_resnet50_bf16_top1_agreement():
+    net, sd = make_victim(compute_dtype="bf16")
+    g = torch.Generator().manual_seed(6)
+    x = torch.rand(8, 3, 224, 224, generator=g)
+    ref = ov.resnet50_forward(sd, x)
+    got = net(x.cuda()).cpu()
+    rel = (got - ref).abs().max().item() / ref.abs().max().item()
+    assert rel < 0.05, rel
+    # decisions agree wherever the fp32 margin between the top two classes exceeds the bf16 noise
+    top2 = ref.topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 0.1 * ref.abs().max()
+    assert torch.equal(got.argmax(1)[clear], ref.argmax(1)[clear])
+
+
+def test_compute_asr_on_a_folder(tmp_path):
+    net, sd = make_victim()
+    rng = np.random.default_rng(0)
+    names = ["Abyssinian_1.jpg", "Bengal_7.png", "american_bulldog_22.png", "notes.txt"]
+    arrs = {}
+    for n in names[:3]:
+        a = rng.integers(0, 256, (96, 120, 3), dtype=np.uint8)
+        Image.fromarray(a).save(tmp_path / n)
+        arrs[n] = np.asarray(Image.open(tmp_path / n).convert("RGB"))
+    (tmp_path / names[3]).write_text("x")
+    # oracle: PIL resize + CPU forward
+    preds = {}
+    for n, a in arrs.items():
+        pil = Image.fromarray(a).resize((224, 224), Image.BILINEAR)
+        x = torch.from_numpy(np.asarray(pil).transpose(2, 0, 1).astype(np.float32) / 255.0)[None]
+        preds[n] = int(ov.resnet50_forward(sd, x).argmax(1))
+    int_to_label = {i: f"class{i}" for i in range(37)}
+    int_to_label[preds["Bengal_7.png"]] = "Bengal"            # make exactly one file a "failed attack"
+    expect = sum(int_to_label[preds[n]] != n.rsplit("_", 1)[0] for n in arrs) / 3
+    got = asr.compute_asr(str(tmp_path), net, int_to_label)
+    assert got == expect
+    x = asr.preprocess_image(str(tmp_path / names[0]))
+    assert x.shape == (1, 3, 224, 224) and x.is_cuda and float(x.max()) <= 1.0
+
+
+def test_label_maps_from_reference_style_config(tmp_path):
+    import json
+    p = tmp_path / "config2.json"
+    p.write_text(json.dumps({"id2label": {"0": "Abyssinian", "1": "Bengal"}}))
+    l2i, i2l = asr.load_label_maps(str(p))
+    assert l2i == {"Abyssinian": 0, "Bengal": 1} and i2l == {0: "Abyssinian", 1: "Bengal"}
