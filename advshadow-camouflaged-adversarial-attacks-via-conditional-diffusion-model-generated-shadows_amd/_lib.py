@@ -43,6 +43,7 @@ SIGNATURES = {
     "advs_timestep_embedding": [vp, vp, i32, i32, vp, vp, vp, i32, vp],
     "advs_ddim_step": [vp, vp, vp, f32, vp, vp, vp, i32, vp, vp, i32, sz, i32, vp],
     "advs_to_uint8": [vp, vp, sz, i32, vp],
+    "advs_unit_to_uint8": [vp, vp, sz, vp],
     "advs_apply_shadow": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, C.POINTER(f32), i32, vp],
     "advs_composite_u8": [vp, vp, vp, vp, sz, i32, f32, vp],
     "advs_resample_u8": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],

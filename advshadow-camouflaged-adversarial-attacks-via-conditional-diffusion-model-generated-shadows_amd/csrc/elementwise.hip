@@ -224,3 +224,20 @@ extern "C" int advs_to_uint8(const float* x, uint8_t* y, size_t n, int clamp, vo
     ADVS_CHECK_LAUNCH("to_uint8");
     return ADVS_OK;
 }
+
+// [0,1] float image -> uint8 as torchvision's ToPILImage does (pic.mul(255).byte(): truncation; values are
+// clamped first because an out-of-range float->uint8 cast is not portable).
+__global__ void unit_to_uint8_kernel(const float* __restrict__ x, uint8_t* __restrict__ y, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float v = x[i] * 255.0f;
+        v = fminf(fmaxf(v, 0.0f), 255.0f);
+        y[i] = (uint8_t)(int)v;
+    }
+}
+extern "C" int advs_unit_to_uint8(const float* x, uint8_t* y, size_t n, void* stream) {
+    ADVS_REQUIRE(x && y && n > 0, "unit_to_uint8: bad args");
+    int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    unit_to_uint8_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, y, n);
+    ADVS_CHECK_LAUNCH("unit_to_uint8");
+    return ADVS_OK;
+}

@@ -139,6 +139,8 @@ int advs_ddim_step(float* x, const float* eps, const float* eps_uncond, float cf
 /* uint8 image = trunc((x+1)*0.5*255) wrapped mod 256 (no clamp: model/samples/ddim.py:97-99),
  * or clamped when clamp != 0.                                                                */
 int advs_to_uint8(const float* x, uint8_t* y, size_t n, int clamp, void* stream);
+/* [0,1] float image -> uint8 by clamp(x*255) truncated (ToPILImage's pic.mul(255).byte()).          */
+int advs_unit_to_uint8(const float* x, uint8_t* y, size_t n, void* stream);
 
 /* ---- shadow composite, image hand-off, metrics ------------------------------------------------
  * Closed form of apply_shadow (tools/train_shadow.py:242-256,262-266; ddim2/test.py:830-871; with

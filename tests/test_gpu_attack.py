@@ -1,0 +1,60 @@
+"""The fused attack loop (sampler -> victim -> ASR; composite -> PSNR/SSIM) on the MI355X against the
+same stages evaluated with the CPU oracles, incl. identical top-1 decisions."""
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+pytestmark = pytest.mark.gpu
+
+from advshadow_amd import attack, parallel  # noqa: E402
+from advshadow_amd.diff_model import GaussianDiffusion, UNetModel  # noqa: E402
+from advshadow_amd.victims import ResNet50  # noqa: E402
+from oracle import lineage_b as ob, metrics as om, shadow as osh, victims as ov  # noqa: E402
+
+
+def test_attack_loop_matches_oracle_pipeline():
+    n, S = 4, 32
+    over = dict(model_channels=64, channel_mult=(1, 2), num_res_blocks=1, attention_resolutions=(2,), num_heads=4)
+    torch.manual_seed(3)
+    net = UNetModel(**over).to("cuda").eval()
+    hp = ob.hparams(**over)
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    torch.manual_seed(1)
+    victim = ResNet50(37)
+    vsd = ov.randomize_bn({k: v.clone() for k, v in victim.state_dict().items()}, 9)
+    victim.load_state_dict(vsd)
+    victim = victim.to("cuda").eval()
+    xT = parallel.image_noise(range(n), (3, S, S))
+    g = torch.Generator().manual_seed(7)
+    clean = torch.rand(n, 3, S, S, generator=g)
+    yy, xx = torch.meshgrid(torch.arange(S), torch.arange(S), indexing="ij")
+    fmask = (((xx - 16.0) ** 2 + (yy - 16.0) ** 2) <= 10 ** 2).float()[None, None].expand(n, 1, S, S).contiguous()
+    centers = torch.tensor([[16.0, 16.0]] * n)
+    radii = torch.tensor([5.0] * n)
+    gd = GaussianDiffusion()
+
+    def sample_fn():
+        x = gd.ddim_sample(net, S, batch_size=n, ddim_timesteps=3, x_T=xT, return_tensor=True)
+        out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+        from advshadow_amd import _lib
+        _lib.check(_lib.load().advs_to_uint8(x.data_ptr(), out.data_ptr(), x.numel(), 1, torch.cuda.current_stream().cuda_stream))
+        return out
+
+    gen, pred, psnr, ssim = attack.attack_shard(sample_fn, victim, clean.cuda(), fmask.cuda(), centers, radii)
+    # ---- oracle pipeline on the CPU
+    xf = torch.from_numpy(ob.ddim_sample(lambda x, t: ob.unet_forward(sd, x, t), xT, steps=3))
+    ref_u8 = (((xf + 1) * 0.5) * 255).clamp(0, 255).type(torch.uint8)
+    d = (gen.cpu().to(torch.int16) - ref_u8.to(torch.int16)).abs()
+    assert d.max().item() <= 1 and (d > 0).float().mean().item() < 0.01
+    for i in range(n):
+        pil = Image.fromarray(gen[i].cpu().numpy().transpose(1, 2, 0)).resize((224, 224), Image.BILINEAR)
+        x = torch.from_numpy(np.asarray(pil).transpose(2, 0, 1).astype(np.float32) / 255.0)[None]
+        assert int(ov.resnet50_forward(vsd, x).argmax(1)) == int(pred[i])          # identical top-1 decision
+        sh = osh.apply_shadow(clean[i], (16.0, 16.0), 5.0, fmask[i], 0.43, 5)
+        to64 = lambda t: np.asarray(Image.fromarray((t * 255).clamp(0, 255).byte().numpy().transpose(1, 2, 0))
+                                    .resize((64, 64), Image.BILINEAR)).transpose(2, 0, 1).astype(np.float32) / 255.0
+        s, p = om.calculate_ssim_psnr(to64(clean[i]), to64(sh), 7)
+        assert abs(float(ssim[i]) - s) < 1e-5 and abs(float(psnr[i]) - p) < 1e-3
+    m, _ = attack.run_attack(n, lambda lo, hi: (gen, pred, psnr, ssim), labels=torch.arange(n) % 37)
+    assert m["n"] == n and 0.0 <= m["asr"] <= 1.0 and m["psnr"] > 0
