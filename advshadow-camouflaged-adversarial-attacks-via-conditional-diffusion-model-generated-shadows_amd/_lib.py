@@ -78,6 +78,10 @@ def load():
     """Load the shared library (once).  Raises if it has not been built."""
     global _lib
     if _lib is None:
+        # torch first: its bundled libamdhip64 (SONAME libamdhip64.so.7) must be the HIP runtime already in
+        # the process when this library's NEEDED libamdhip64.so.7 is resolved, otherwise the system copy is
+        # loaded beside torch's and streams / device pointers would cross two runtimes.
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise AdvsError(f"{LIB_PATH} is missing: build it with __graft_entry__.build() "
                             f"(hipcc --offload-arch=gfx950); there is no CPU fallback")

@@ -35,7 +35,7 @@ def test_attack_loop_matches_oracle_pipeline():
     gd = GaussianDiffusion()
 
     def sample_fn():
-        x = gd.ddim_sample(net, S, batch_size=n, ddim_timesteps=3, x_T=xT, return_tensor=True)
+        x = gd.ddim_sample(net, S, batch_size=n, ddim_timesteps=4, x_T=xT, return_tensor=True)
         out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
         from advshadow_amd import _lib
         _lib.check(_lib.load().advs_to_uint8(x.data_ptr(), out.data_ptr(), x.numel(), 1, torch.cuda.current_stream().cuda_stream))
@@ -43,7 +43,7 @@ def test_attack_loop_matches_oracle_pipeline():
 
     gen, pred, psnr, ssim = attack.attack_shard(sample_fn, victim, clean.cuda(), fmask.cuda(), centers, radii)
     # ---- oracle pipeline on the CPU
-    xf = torch.from_numpy(ob.ddim_sample(lambda x, t: ob.unet_forward(sd, x, t), xT, steps=3))
+    xf = torch.from_numpy(ob.ddim_sample(lambda x, t: ob.unet_forward(sd, hp, x, t), xT, steps=4))
     ref_u8 = (((xf + 1) * 0.5) * 255).clamp(0, 255).type(torch.uint8)
     d = (gen.cpu().to(torch.int16) - ref_u8.to(torch.int16)).abs()
     assert d.max().item() <= 1 and (d > 0).float().mean().item() < 0.01
