@@ -4,9 +4,11 @@
 //   m = (b, oy, ox) output pixel, n = output channel, k = (r, s, c) filter tap x input channel.
 //
 // A is never materialised: every 128-byte K-slab of an A row is one contiguous NHWC channel
-// run of one source pixel (or the zero page outside the image), fetched straight into LDS by
-// global_load_lds (16 B per lane, per-lane source address = the im2col gather).  The gather
-// also performs the channel concat of two sources and the nearest x2 upsample.
+// run of one source pixel, fetched straight into LDS by `buffer_load_dwordx4 ... lds` (16 B per
+// lane; the per-lane byte offset IS the im2col gather, and rows outside the image carry an
+// out-of-range offset so the buffer bounds check writes zeros).  The gather also performs the
+// channel concat of two sources and the nearest x2 upsample.  Offsets are recomputed only when
+// the filter tap or the concat source changes; within a tap a slab is one scalar-offset bump.
 //
 // Tile BM x BN x 128 B of K per step, NW waves each owning a WM x WN block of 32x32 MFMA
 // tiles.  bf16: v_mfma_f32_32x32x16_bf16; f32: v_mfma_f32_32x32x2_f32 (exact f32).
@@ -22,22 +24,37 @@
 
 #define SLAB 128                 // bytes of K per row per step
 
+// Division by a launch-invariant divisor (Granlund-Montgomery): q = (umulhi(n, m) + n) >> s, exact
+// for n < 2^31.  Replaces ~35-instruction integer divides in the tile prologue / epilogue.
+struct FastDiv {
+    unsigned d, m, s;
+    __host__ void init(unsigned dd) {
+        d = dd; s = 0;
+        while ((1ull << s) < dd) ++s;
+        m = (unsigned)(((1ull << 32) * ((1ull << s) - dd)) / dd + 1);
+    }
+    __device__ __forceinline__ unsigned div(unsigned n) const { return (__umulhi(n, m) + n) >> s; }
+};
+
 struct ConvKP {
     const char* x1; const char* x2; const char* w;
     const float* bias; const float* temb; const char* res; char* y;
-    const char* zero;
+    unsigned x1_bytes, x2_bytes, w_bytes;
     int B, H, W, C1, C2, Cout;
     int R, stride, pad, ups;
     int Ho, Wo, M, K;            // K in elements
     int act, temb_stride;
     int nMt, nNt;
+    FastDiv dHoWo, dWo;
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
-__device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)lds_wave_base, 16, 0, 0);
+#define OOB_OFFSET 0xF0000000u   // > every num_records we accept: the bounds check returns zeros
+
+__device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, char* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)lds_wave_base, 16, voff, soff, 0, 0);
 }
 
 template <typename T> struct Mma;
@@ -58,7 +75,7 @@ template <> struct Mma<float> {
     }
 };
 
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, int NSTAGE>
 __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
 conv_igemm_kernel(const ConvKP p) {
     constexpr int ESZ = Mma<T>::ESZ;
@@ -69,8 +86,9 @@ conv_igemm_kernel(const ConvKP p) {
     constexpr int TM = WM / 32, TN = WN / 32;             // MFMA tiles per wave
     constexpr int A_BYTES = BM * SLAB, B_BYTES = BN * SLAB, STAGE = A_BYTES + B_BYTES;
     static_assert(AR * NT == BM * 8 && BR * NT == BN * 8, "tile/wave geometry");
-    static_assert(NW * 32 * WN * 4 <= 2 * STAGE, "epilogue patches must fit the staging buffers");
-    extern __shared__ __attribute__((aligned(1024))) char smem[];   // [2][A tile | B tile]
+    static_assert(NW * 32 * WN * 4 <= NSTAGE * STAGE, "epilogue patches must fit the staging buffers");
+    static_assert(NSTAGE == 2 || NSTAGE == 3, "2- or 3-deep LDS ring");
+    extern __shared__ __attribute__((aligned(1024))) char smem[];   // [NSTAGE][A tile | B tile]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -91,17 +109,17 @@ conv_igemm_kernel(const ConvKP p) {
     const int Cin = p.C1 + p.C2;
     const int HL = p.H << p.ups, WL = p.W << p.ups;
     const int chunk = lane & 7;
-    int a_b[AR], a_iy[AR], a_ix[AR], a_csw[AR];
-    const char* b_src[BR];
-    int b_csw[BR];
+    int a_b[AR], a_iy[AR], a_ix[AR];
+    unsigned a_csw[AR], a_voff[AR], b_voff[BR];
 #pragma unroll
     for (int j = 0; j < AR; ++j) {
         const int row = (wave * AR + j) * 8 + (lane >> 3);
         a_csw[j] = ((chunk ^ ((row >> 1) & 7)) << 4);
+        a_voff[j] = OOB_OFFSET;
         const int m = m0 + row;
         if (m < p.M) {
-            const int b = m / HoWo, rem = m - b * HoWo;
-            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            const int b = (int)p.dHoWo.div((unsigned)m), rem = m - b * HoWo;
+            const int oy = (int)p.dWo.div((unsigned)rem), ox = rem - oy * p.Wo;
             a_b[j] = b; a_iy[j] = oy * p.stride - p.pad; a_ix[j] = ox * p.stride - p.pad;
         } else {
             a_b[j] = 0; a_iy[j] = -0x40000000; a_ix[j] = 0;      // always out of the image
@@ -110,10 +128,12 @@ conv_igemm_kernel(const ConvKP p) {
 #pragma unroll
     for (int j = 0; j < BR; ++j) {
         const int row = (wave * BR + j) * 8 + (lane >> 3);
-        b_csw[j] = ((chunk ^ ((row >> 1) & 7)) << 4);
         const int n = n0 + row;
-        b_src[j] = (n < p.Cout) ? p.w + ((size_t)n * p.K) * ESZ + b_csw[j] : nullptr;
+        b_voff[j] = (n < p.Cout) ? (unsigned)n * (unsigned)p.K * ESZ + ((chunk ^ ((row >> 1) & 7)) << 4) : OOB_OFFSET;
     }
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x1, 0, p.x1_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x2 ? p.x2 : p.x1), 0, p.x2_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
 
     // K-slab cursor (uniform): tap (r, s) and channel offset c0 inside the concatenated input
     int kr = 0, ks = 0, c0 = 0;
@@ -123,22 +143,28 @@ conv_igemm_kernel(const ConvKP p) {
         char* la = smem + buf * STAGE;
         char* lb = la + A_BYTES;
         const bool first = c0 < p.C1;
-        const char* src = first ? p.x1 : p.x2;
-        const int cs = first ? p.C1 : p.C2;
-        const int cc = first ? c0 : c0 - p.C1;
+        if (c0 == 0 || c0 == p.C1) {
+            // new (tap, source) segment: per-row byte offset of the source pixel, or out of range
+            const unsigned cs = (unsigned)(first ? p.C1 : p.C2) * ESZ;
 #pragma unroll
-        for (int j = 0; j < AR; ++j) {
-            const int iy = a_iy[j] + kr, ix = a_ix[j] + ks;
-            const bool ok = (unsigned)iy < (unsigned)HL && (unsigned)ix < (unsigned)WL;
-            const size_t pix = ((size_t)a_b[j] * p.H + (iy >> p.ups)) * p.W + (ix >> p.ups);
-            const char* s = ok ? src + (pix * cs + cc) * ESZ + a_csw[j] : p.zero + a_csw[j];
-            glds16(s, la + (wave * AR + j) * 1024);
+            for (int j = 0; j < AR; ++j) {
+                const int iy = a_iy[j] + kr, ix = a_ix[j] + ks;
+                const bool ok = (unsigned)iy < (unsigned)HL && (unsigned)ix < (unsigned)WL;
+                const unsigned pix = (unsigned)((a_b[j] * p.H + (iy >> p.ups)) * p.W + (ix >> p.ups));
+                a_voff[j] = ok ? pix * cs + a_csw[j] : OOB_OFFSET;
+            }
         }
+        const unsigned soff = (unsigned)(first ? c0 : c0 - p.C1) * ESZ;
+        if (first) {
 #pragma unroll
-        for (int j = 0; j < BR; ++j) {
-            const char* s = b_src[j] ? b_src[j] + (size_t)kt * SLAB : p.zero + b_csw[j];
-            glds16(s, lb + (wave * BR + j) * 1024);
+            for (int j = 0; j < AR; ++j) blds16(rs1, a_voff[j], soff, la + (wave * AR + j) * 1024);
+        } else {
+#pragma unroll
+            for (int j = 0; j < AR; ++j) blds16(rs2, a_voff[j], soff, la + (wave * AR + j) * 1024);
         }
+        const unsigned woff = (unsigned)kt * SLAB;
+#pragma unroll
+        for (int j = 0; j < BR; ++j) blds16(rsw, b_voff[j], woff, lb + (wave * BR + j) * 1024);
         c0 += BKE;
         if (c0 == Cin) { c0 = 0; if (++ks == p.R) { ks = 0; ++kr; } }
     };
@@ -166,32 +192,66 @@ conv_igemm_kernel(const ConvKP p) {
         b_off[j] = rb * SLAB; b_sw[j] = (rb >> 1) & 7;
     }
 
-    stage(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) {
-            stage(buf ^ 1, kt + 1);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AR + BR) : "memory");   // slab kt landed, kt+1 in flight
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (NSTAGE == 2) {
+        // two buffers, two barriers per slab: slab kt+1 is in flight while slab kt is consumed
+        stage(0, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) {
+                stage(buf ^ 1, kt + 1);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AR + BR) : "memory");   // slab kt landed, kt+1 in flight
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            const char* la = smem + buf * STAGE;
+            const char* lb = la + A_BYTES;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                u32x4 af[TM], bf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = *(const u32x4*)(la + a_off[i] + (((2 * s + lh) ^ a_sw[i]) << 4));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[j] = *(const u32x4*)(lb + b_off[j] + (((2 * s + lh) ^ b_sw[j]) << 4));
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) Mma<T>::run(af[i], bf[j], acc[i][j]);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this wave's LDS reads retired ...
+            __builtin_amdgcn_s_barrier();                            // ... before anyone restages buf
         }
-        __builtin_amdgcn_s_barrier();
-        const char* la = smem + buf * STAGE;
-        const char* lb = la + A_BYTES;
+    } else {
+        // three buffers, ONE barrier per slab, two slabs in flight: passing the barrier of iteration
+        // kt proves every wave's share of slab kt has landed (each waited its own vmcnt first) and
+        // every wave has finished reading slab kt-1, whose buffer is restaged right after.
+        stage(0, 0);
+        if (nk > 1) stage(1, 1);
+        int buf = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AR + BR) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + 2 < nk) stage(buf == 0 ? 2 : buf - 1, kt + 2);   // (kt+2) % 3 == (kt-1) % 3
+            const char* la = smem + buf * STAGE;
+            const char* lb = la + A_BYTES;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            u32x4 af[TM], bf[TN];
+            for (int s = 0; s < 4; ++s) {
+                u32x4 af[TM], bf[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *(const u32x4*)(la + a_off[i] + (((2 * s + lh) ^ a_sw[i]) << 4));
+                for (int i = 0; i < TM; ++i) af[i] = *(const u32x4*)(la + a_off[i] + (((2 * s + lh) ^ a_sw[i]) << 4));
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *(const u32x4*)(lb + b_off[j] + (((2 * s + lh) ^ b_sw[j]) << 4));
+                for (int j = 0; j < TN; ++j) bf[j] = *(const u32x4*)(lb + b_off[j] + (((2 * s + lh) ^ b_sw[j]) << 4));
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) Mma<T>::run(af[i], bf[j], acc[i][j]);
+                    for (int j = 0; j < TN; ++j) Mma<T>::run(af[i], bf[j], acc[i][j]);
+            }
+            buf = buf == 2 ? 0 : buf + 1;
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this wave's LDS reads retired ...
-        __builtin_amdgcn_s_barrier();                            // ... before anyone restages buf
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                // all reads done before the patches reuse LDS
     }
 
     // ---- epilogue.  C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
@@ -233,7 +293,7 @@ conv_igemm_kernel(const ConvKP p) {
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) v[e] += bias[e];
                 if (p.temb) {
-                    const float* tp = p.temb + (size_t)(m / HoWo) * p.temb_stride + n;
+                    const float* tp = p.temb + (size_t)p.dHoWo.div((unsigned)m) * p.temb_stride + n;
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) v[e] += tp[e];
                 }
@@ -256,18 +316,18 @@ conv_igemm_kernel(const ConvKP p) {
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, int NSTAGE = 2>
 static int conv_launch(ConvKP& p, hipStream_t st) {
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
-    constexpr int lds = 2 * (BM + BN) * SLAB;
+    constexpr int lds = NSTAGE * (BM + BN) * SLAB;
     static bool attr_set = false;
     if (!attr_set) {
-        ADVS_HIP(hipFuncSetAttribute((const void*)conv_igemm_kernel<T, BM, BN, WM, WN>,
+        ADVS_HIP(hipFuncSetAttribute((const void*)conv_igemm_kernel<T, BM, BN, WM, WN, NSTAGE>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
     p.nMt = cdiv(p.M, BM); p.nNt = cdiv(p.Cout, BN);
-    conv_igemm_kernel<T, BM, BN, WM, WN><<<p.nMt * p.nNt, NT, lds, st>>>(p);
+    conv_igemm_kernel<T, BM, BN, WM, WN, NSTAGE><<<p.nMt * p.nNt, NT, lds, st>>>(p);
     ADVS_CHECK_LAUNCH("conv_igemm");
     return ADVS_OK;
 }
@@ -286,6 +346,9 @@ static int conv_dispatch(ConvKP& p, int tile, hipStream_t st) {
         case 2: return conv_launch<T, 256, 128, 64, 64>(p, st);
         case 3: return conv_launch<T, 256, 128, 128, 64>(p, st);
         case 4: return conv_launch<T, 256, 256, 128, 64>(p, st);
+        case 5: return conv_launch<T, 256, 128, 64, 64, 3>(p, st);
+        case 6: return conv_launch<T, 128, 128, 64, 64, 3>(p, st);
+        case 7: return conv_launch<T, 256, 128, 128, 64, 3>(p, st);
         default: ADVS_FAIL(ADVS_ERR_ARG, "conv2d: unknown tile id %d", tile);
     }
 }
@@ -305,12 +368,9 @@ extern "C" int advs_conv2d(const advs_conv_args* a, void* stream) {
     ADVS_REQUIRE(a->c1 % bke == 0 && a->c2 % bke == 0, "conv2d: channels (%d,%d) must be multiples of %d",
                  a->c1, a->c2, bke);
     ADVS_REQUIRE(a->cout % (16 / esz) == 0, "conv2d: cout=%d must be a multiple of %d", a->cout, 16 / esz);
-    const void* zero = advs_zero_page();
-    ADVS_REQUIRE(zero, "conv2d: advs_init() has not been called on this device");
     ConvKP p;
     p.x1 = (const char*)a->x1; p.x2 = (const char*)a->x2; p.w = (const char*)a->w;
     p.bias = a->bias; p.temb = a->temb; p.res = (const char*)a->residual; p.y = (char*)a->y;
-    p.zero = (const char*)zero;
     p.B = a->b; p.H = a->h; p.W = a->w_; p.C1 = a->c1; p.C2 = a->c2; p.Cout = a->cout;
     p.R = a->ksize; p.stride = a->stride; p.pad = a->pad; p.ups = a->upsample ? 1 : 0;
     const int HL = a->h << p.ups, WL = a->w_ << p.ups;
@@ -320,7 +380,14 @@ extern "C" int advs_conv2d(const advs_conv_args* a, void* stream) {
     ADVS_REQUIRE(M > 0 && M < (1ll << 31) - 256, "conv2d: M=%lld out of range", M);
     p.M = (int)M;
     p.K = a->ksize * a->ksize * (a->c1 + a->c2);
+    const unsigned long long x1b = (unsigned long long)a->b * a->h * a->w_ * a->c1 * esz;
+    const unsigned long long x2b = (unsigned long long)a->b * a->h * a->w_ * a->c2 * esz;
+    const unsigned long long wb = (unsigned long long)a->cout * p.K * esz;
+    ADVS_REQUIRE(x1b < 0xF0000000ull && x2b < 0xF0000000ull && wb < 0xF0000000ull,
+                 "conv2d: a source of %llu bytes exceeds the 32-bit buffer offsets (split the batch)", x1b > x2b ? x1b : x2b);
+    p.x1_bytes = (unsigned)x1b; p.x2_bytes = (unsigned)(a->x2 ? x2b : x1b); p.w_bytes = (unsigned)wb;
     p.act = a->act; p.temb_stride = a->temb_stride > 0 ? a->temb_stride : a->cout;
+    p.dHoWo.init((unsigned)(p.Ho * p.Wo)); p.dWo.init((unsigned)p.Wo);
     const int tile = g_tile_override ? g_tile_override : a->tile;
     if (a->dtype == ADVS_BF16) return conv_dispatch<BF16>(p, tile, (hipStream_t)stream);
     return conv_dispatch<float>(p, tile, (hipStream_t)stream);
