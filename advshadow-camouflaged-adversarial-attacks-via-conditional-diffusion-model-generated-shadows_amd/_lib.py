@@ -20,7 +20,7 @@ class ConvArgs(C.Structure):
     _fields_ = [("x1", vp), ("x2", vp), ("w", vp), ("bias", vp), ("temb", vp), ("residual", vp), ("y", vp),
                 ("b", i32), ("h", i32), ("w_", i32), ("c1", i32), ("c2", i32), ("cout", i32),
                 ("ksize", i32), ("stride", i32), ("pad", i32), ("upsample", i32),
-                ("act", i32), ("dtype", i32), ("temb_stride", i32), ("tile", i32)]
+                ("act", i32), ("dtype", i32), ("temb_stride", i32), ("tile", i32), ("stats", vp)]
 
 
 # name -> argtypes (restype is int unless listed in _RESTYPES)
@@ -32,6 +32,9 @@ SIGNATURES = {
     "advs_nhwc_to_nchw_f32": [vp, vp, i32, i32, i32, i32, i32, vp],
     "advs_conv2d": [C.POINTER(ConvArgs), vp],
     "advs_conv_set_tile": [i32],
+    "advs_conv_pick_tile": [C.c_longlong, i32],
+    "advs_conv_tile_rows": [i32],
+    "advs_groupnorm_stats": [vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "advs_conv3x3_first": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "advs_conv_last": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "advs_groupnorm": [vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],

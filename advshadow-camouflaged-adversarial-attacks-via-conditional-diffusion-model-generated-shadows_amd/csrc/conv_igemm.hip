@@ -19,6 +19,9 @@
 // temb / residual are read and y is written as 16-byte vectors along the channel axis
 // (whole 128-byte lines), instead of one element per lane.
 //
+// Optionally the epilogue also emits, per WM-row block and channel, the sum and sum of squares of the
+// stored values: the GroupNorm that consumes y then needs no statistics pass over the tensor.
+//
 // Roofline: MFMA-bound.  Algorithmic FLOPs per launch = 2*M*N*K.
 #include "common.h"
 
@@ -39,6 +42,7 @@ struct FastDiv {
 struct ConvKP {
     const char* x1; const char* x2; const char* w;
     const float* bias; const float* temb; const char* res; char* y;
+    float* stats;                // [ceil(M/WM)][Cout][2] per-channel (sum, sum of squares) of y, or null
     unsigned x1_bytes, x2_bytes, w_bytes;
     int B, H, W, C1, C2, Cout;
     int R, stride, pad, ups;
@@ -265,9 +269,9 @@ conv_igemm_kernel(const ConvKP p) {
     const int prow = lane / LPR, pcv = lane - prow * LPR;
     const int n = n0 + wc * WN + pcv * VEC;
     const bool n_ok = n < p.Cout;                 // Cout is a multiple of VEC
-    float bias[VEC];
+    float bias[VEC], ssum[VEC], ssq[VEC];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) bias[e] = (p.bias && n_ok) ? p.bias[n + e] : 0.f;
+    for (int e = 0; e < VEC; ++e) { bias[e] = (p.bias && n_ok) ? p.bias[n + e] : 0.f; ssum[e] = 0.f; ssq[e] = 0.f; }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -307,12 +311,32 @@ conv_igemm_kernel(const ConvKP p) {
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) v[e] = apply_act(v[e], p.act);
                 }
-                *(u32x4*)(y + o) = pack16<T>(v);
+                const u32x4 packed = pack16<T>(v);
+                *(u32x4*)(y + o) = packed;
+                if (p.stats) {                    // statistics of the values as stored (after rounding)
+                    float sv[VEC];
+                    unpack16<T>(packed, sv);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) { ssum[e] += sv[e]; ssq[e] = fmaf(sv[e], sv[e], ssq[e]); }
+                }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (p.stats) {
+        // fold the RPI row-lanes that share a channel vector (fixed butterfly order), lanes 0..LPR-1 store
+#pragma unroll
+        for (int o = LPR; o < 64; o <<= 1)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { ssum[e] += __shfl_xor(ssum[e], o); ssq[e] += __shfl_xor(ssq[e], o); }
+        if (prow == 0 && n_ok && m0 + wr * WM < p.M) {          // row blocks past M do not exist
+            const int rb = (m0 + wr * WM) / WM;
+            float* sp = p.stats + ((size_t)rb * p.Cout + n) * 2;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { sp[2 * e] = ssum[e]; sp[2 * e + 1] = ssq[e]; }
+        }
     }
 }
 
@@ -332,15 +356,11 @@ static int conv_launch(ConvKP& p, hipStream_t st) {
     return ADVS_OK;
 }
 
+static int pick_tile(long long M, int cout);
+
 template <typename T>
 static int conv_dispatch(ConvKP& p, int tile, hipStream_t st) {
-    if (tile == 0) {
-        // measured on MI355X (tools/tune_conv.py, round 1): the 256x256 tile wins (~1.0-1.06 vs
-        // ~0.85 PFLOP/s) whenever Cout fills it and M still yields >= 1.5 blocks per CU; the
-        // 128x128 tile at two blocks per CU wins everywhere else, including Cout = 128.
-        const long long blocks256 = (long long)cdiv(p.M, 256) * cdiv(p.Cout, 256);
-        tile = (p.Cout % 256 == 0 && blocks256 >= 384) ? 4 : 1;
-    }
+    if (tile == 0) tile = pick_tile(p.M, p.Cout);
     switch (tile) {
         case 1: return conv_launch<T, 128, 128, 64, 64>(p, st);
         case 2: return conv_launch<T, 256, 128, 64, 64>(p, st);
@@ -355,6 +375,19 @@ static int conv_dispatch(ConvKP& p, int tile, hipStream_t st) {
 
 static int g_tile_override = 0;
 extern "C" int advs_conv_set_tile(int tile) { g_tile_override = tile; return ADVS_OK; }
+
+static int pick_tile(long long M, int cout) {
+    // measured on MI355X (tools/tune_conv.py, round 1): the 256x256 tile wins (~1.05-1.15 vs
+    // ~1.0 PFLOP/s) whenever Cout fills it and M still yields >= 1.5 blocks per CU; the
+    // 128x128 tile at two blocks per CU wins everywhere else, including Cout = 128.
+    const long long blocks256 = (long long)cdiv(M, 256) * cdiv(cout, 256);
+    return (cout % 256 == 0 && blocks256 >= 384) ? 4 : 1;
+}
+/* tile id advs_conv2d would choose for an M x cout output, and the row-block height (WM) of a tile id */
+extern "C" int advs_conv_pick_tile(long long m, int cout) { return g_tile_override ? g_tile_override : pick_tile(m, cout); }
+extern "C" int advs_conv_tile_rows(int tile) {
+    switch (tile) { case 1: case 2: case 5: case 6: return 64; case 3: case 4: case 7: return 128; default: return 0; }
+}
 
 extern "C" int advs_conv2d(const advs_conv_args* a, void* stream) {
     ADVS_REQUIRE(a && a->x1 && a->w && a->y, "conv2d: null pointer");
@@ -371,6 +404,7 @@ extern "C" int advs_conv2d(const advs_conv_args* a, void* stream) {
     ConvKP p;
     p.x1 = (const char*)a->x1; p.x2 = (const char*)a->x2; p.w = (const char*)a->w;
     p.bias = a->bias; p.temb = a->temb; p.res = (const char*)a->residual; p.y = (char*)a->y;
+    p.stats = a->stats;
     p.B = a->b; p.H = a->h; p.W = a->w_; p.C1 = a->c1; p.C2 = a->c2; p.Cout = a->cout;
     p.R = a->ksize; p.stride = a->stride; p.pad = a->pad; p.ups = a->upsample ? 1 : 0;
     const int HL = a->h << p.ups, WL = a->w_ << p.ups;
@@ -389,6 +423,11 @@ extern "C" int advs_conv2d(const advs_conv_args* a, void* stream) {
     p.act = a->act; p.temb_stride = a->temb_stride > 0 ? a->temb_stride : a->cout;
     p.dHoWo.init((unsigned)(p.Ho * p.Wo)); p.dWo.init((unsigned)p.Wo);
     const int tile = g_tile_override ? g_tile_override : a->tile;
+    if (p.stats) {
+        const int wm = advs_conv_tile_rows(tile ? tile : pick_tile(p.M, p.Cout));
+        ADVS_REQUIRE(wm > 0 && (p.Ho * p.Wo) % wm == 0, "conv2d: stats need Ho*Wo (%d) to be a multiple of the tile's row block (%d)",
+                     p.Ho * p.Wo, wm);
+    }
     if (a->dtype == ADVS_BF16) return conv_dispatch<BF16>(p, tile, (hipStream_t)stream);
     return conv_dispatch<float>(p, tile, (hipStream_t)stream);
 }

@@ -94,11 +94,17 @@ __global__ void __launch_bounds__(GN_THREADS)
 gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ x2, int C1, const float* __restrict__ gamma,
                 const float* __restrict__ beta, const T* __restrict__ res, T* __restrict__ y,
                 const float* __restrict__ partials, int HW, int C, int G, int nchunk, int nblk, int act,
-                const float* __restrict__ cadd, int cadd_stride) {
+                const float* __restrict__ cadd, int cadd_stride, const float* __restrict__ meanrstd) {
     constexpr int VEC = Elt<T>::VEC;
     __shared__ float s_mean[64], s_rstd[64];
     const int vpp = C / VEC, PIXB = GN_THREADS / vpp;
     const int b = blockIdx.y, tid = threadIdx.x, cpg = C / G;
+    if (meanrstd) {
+        for (int g = tid; g < G; g += GN_THREADS) {
+            s_mean[g] = meanrstd[((size_t)b * G + g) * 2];
+            s_rstd[g] = meanrstd[((size_t)b * G + g) * 2 + 1];
+        }
+    } else
     for (int g = tid; g < G; g += GN_THREADS) {
         double a = 0.0, d = 0.0;
         const float* p = partials + ((size_t)b * nchunk * G + g) * 2;
@@ -130,28 +136,91 @@ gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ x2, int C1, const
                           : (const u32x4*)x2 + (size_t)b * HW * (vpp - v1) + (cv - v1);
     const u32x4* rb = res ? (const u32x4*)res + sample + cv : nullptr;
     u32x4* yb = (u32x4*)y + sample + cv;
-    for (int p = p0 + pl; p < p1; p += PIXB) {
+    auto one = [&](const u32x4& raw, const u32x4& rraw) -> u32x4 {
         float f[VEC], r[VEC];
-        unpack16<T>(xb[(size_t)p * vs], f);
-        if (rb) unpack16<T>(rb[(size_t)p * vpp], r);
+        unpack16<T>(raw, f);
+        if (rb) unpack16<T>(rraw, r);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             float v = fmaf(f[j], ca[j], cb[j]);
             if (rb) v += r[j];
-            f[j] = apply_act(v, act) + cc[j];
+            f[j] = apply_act_t<T>(v, act) + cc[j];
         }
-        yb[(size_t)p * vpp] = pack16<T>(f);
+        return pack16<T>(f);
+    };
+    int p = p0 + pl;
+    for (; p + 3 * PIXB < p1; p += 4 * PIXB) {                     // four 16-byte loads in flight per lane
+        const size_t i0 = (size_t)p * vs, i1 = (size_t)(p + PIXB) * vs, i2 = (size_t)(p + 2 * PIXB) * vs,
+                     i3 = (size_t)(p + 3 * PIXB) * vs;
+        const u32x4 a0 = xb[i0], a1 = xb[i1], a2 = xb[i2], a3 = xb[i3];
+        u32x4 r0 = a0, r1 = a0, r2 = a0, r3 = a0;
+        if (rb) {
+            r0 = rb[(size_t)p * vpp]; r1 = rb[(size_t)(p + PIXB) * vpp];
+            r2 = rb[(size_t)(p + 2 * PIXB) * vpp]; r3 = rb[(size_t)(p + 3 * PIXB) * vpp];
+        }
+        yb[(size_t)p * vpp] = one(a0, r0);
+        yb[(size_t)(p + PIXB) * vpp] = one(a1, r1);
+        yb[(size_t)(p + 2 * PIXB) * vpp] = one(a2, r2);
+        yb[(size_t)(p + 3 * PIXB) * vpp] = one(a3, r3);
+    }
+    for (; p < p1; p += PIXB) {
+        const u32x4 a0 = xb[(size_t)p * vs];
+        const u32x4 r0 = rb ? rb[(size_t)p * vpp] : a0;
+        yb[(size_t)p * vpp] = one(a0, r0);
+    }
+}
+
+// Statistics already emitted by the producing conv epilogues (advs_conv_args.stats): per source a
+// [row blocks][C][2] array of per-channel (sum, sum of squares).  One workgroup per (group, sample)
+// folds them in a fixed order and writes (mean, rstd).
+__global__ void __launch_bounds__(256)
+gn_finalize_kernel(const float* __restrict__ st1, int rbpi1, int C1, const float* __restrict__ st2, int rbpi2, int C2,
+                   float* __restrict__ meanrstd, int HW, int G) {
+    __shared__ double rs[256], rq[256];
+    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int C = C1 + C2, cpg = C / G;
+    double s = 0.0, q = 0.0;
+    for (int cc = 0; cc < cpg; ++cc) {
+        const int c = g * cpg + cc;
+        const bool in1 = c < C1;
+        const float* st = in1 ? st1 : st2;
+        const int rb = in1 ? rbpi1 : rbpi2, Cs = in1 ? C1 : C2, cl = in1 ? c : c - C1;
+        for (int r = tid; r < rb; r += 256) {
+            const float* e = st + (((size_t)b * rb + r) * Cs + cl) * 2;
+            s += (double)e[0]; q += (double)e[1];
+        }
+    }
+    rs[tid] = s; rq[tid] = q;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) { rs[tid] += rs[tid + o]; rq[tid] += rq[tid + o]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double n = (double)HW * cpg, mean = rs[0] / n;
+        double var = rq[0] / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        meanrstd[((size_t)b * G + g) * 2] = (float)mean;
+        meanrstd[((size_t)b * G + g) * 2 + 1] = (float)(1.0 / sqrt(var + 1e-5));
     }
 }
 
 template <typename T>
 static int gn_launch(const void* x, const void* x2, int c1, const float* gamma, const float* beta, const void* res,
                      void* y, float* partials, int b, int hw, int c, int groups, int act, const float* cadd,
-                     int cadd_stride, hipStream_t st) {
+                     int cadd_stride, hipStream_t st, const float* st1 = nullptr, int rbpi1 = 0,
+                     const float* st2 = nullptr, int rbpi2 = 0) {
     constexpr int VEC = Elt<T>::VEC;
     const int vpp = c / VEC, PIXB = GN_THREADS / vpp;
+    const float* meanrstd = nullptr;
+    int nchunk = 1;
+    if (st1) {
+        gn_finalize_kernel<<<dim3(groups, b), 256, 0, st>>>(st1, rbpi1, c1, st2, rbpi2, c - c1, partials, hw, groups);
+        ADVS_CHECK_LAUNCH("gn_finalize");
+        meanrstd = partials;
+    } else {
     // enough chunks to fill 256 CUs several times over, but >= 4 pixels per lane per chunk
-    int nchunk = 2048 / b;
+    nchunk = 2048 / b;
     int maxc = hw / (PIXB * 4);
     if (nchunk > maxc) nchunk = maxc;
     if (nchunk > GN_MAX_CHUNKS) nchunk = GN_MAX_CHUNKS;
@@ -159,13 +228,14 @@ static int gn_launch(const void* x, const void* x2, int c1, const float* gamma, 
     size_t lds = (size_t)PIXB * c * 2 * sizeof(float);
     gn_partial_kernel<T><<<dim3(nchunk, b), GN_THREADS, lds, st>>>((const T*)x, (const T*)x2, c1, partials, hw, c, groups, nchunk);
     ADVS_CHECK_LAUNCH("gn_partial");
+    }
     int nblk = 4096 / b;
     int maxb = hw / (PIXB * 2);
     if (nblk > maxb) nblk = maxb;
     if (nblk < 1) nblk = 1;
     gn_apply_kernel<T><<<dim3(nblk, b), GN_THREADS, 0, st>>>((const T*)x, (const T*)x2, c1, gamma, beta, (const T*)res,
                                                              (T*)y, partials, hw, c, groups, nchunk, nblk, act,
-                                                             cadd, cadd_stride);
+                                                             cadd, cadd_stride, meanrstd);
     ADVS_CHECK_LAUNCH("gn_apply");
     return ADVS_OK;
 }
@@ -187,4 +257,25 @@ extern "C" int advs_groupnorm(const void* x, const void* x2, const float* gamma,
                                chan_add, chan_add_stride, (hipStream_t)stream);
     return gn_launch<float>(x, x2, c1, gamma, beta, residual_in, y, (float*)partials, b, hw, c, groups, act,
                             chan_add, chan_add_stride, (hipStream_t)stream);
+}
+
+// Same as advs_groupnorm, but the per-channel statistics were already emitted by the conv
+// epilogues that produced x (and x2): no pass over the tensors for statistics.
+extern "C" int advs_groupnorm_stats(const void* x, const void* x2, const float* stats1, int row_blocks_per_image1,
+                                    const float* stats2, int row_blocks_per_image2, const float* gamma,
+                                    const float* beta, const void* residual_in, const float* chan_add,
+                                    int chan_add_stride, void* y, void* scratch, int b, int hw, int c1, int c2,
+                                    int groups, int act, int dtype, void* stream) {
+    ADVS_REQUIRE(x && gamma && beta && y && scratch && stats1 && row_blocks_per_image1 > 0, "groupnorm_stats: null pointer");
+    ADVS_REQUIRE(c1 > 0 && c2 >= 0 && (c2 == 0) == (x2 == nullptr) && (c2 == 0) == (stats2 == nullptr),
+                 "groupnorm_stats: x2/c2/stats2 mismatch");
+    const int c = c1 + c2;
+    ADVS_REQUIRE(b > 0 && hw > 0 && groups > 0 && groups <= 64 && c % groups == 0, "groupnorm_stats: bad shape");
+    const int vec = dtype == ADVS_BF16 ? 8 : 4;
+    ADVS_REQUIRE(c1 % vec == 0 && c2 % vec == 0 && c / vec <= GN_THREADS, "groupnorm_stats: c=%d+%d unsupported", c1, c2);
+    if (dtype == ADVS_BF16)
+        return gn_launch<BF16>(x, x2, c1, gamma, beta, residual_in, y, (float*)scratch, b, hw, c, groups, act, chan_add,
+                               chan_add_stride, (hipStream_t)stream, stats1, row_blocks_per_image1, stats2, row_blocks_per_image2);
+    return gn_launch<float>(x, x2, c1, gamma, beta, residual_in, y, (float*)scratch, b, hw, c, groups, act, chan_add,
+                            chan_add_stride, (hipStream_t)stream, stats1, row_blocks_per_image1, stats2, row_blocks_per_image2);
 }

@@ -281,7 +281,8 @@ def emit_unet_forward(bld, model, W, x_nchw, t_dev, eps_out):
     def res_block(p, cin, cout, x1, x2):
         a1 = bld.groupnorm(x1, W[p + ".conv1.0.g"], W[p + ".conv1.0.b"], 32, act="silu", x2=x2)
         o = W["temb_off"][p]
-        h1 = bld.conv(a1, W[p + ".conv1.2.w"], cout, bias=W[p + ".conv1.2.b"], temb=temb[:, o:o + cout], temb_stride=tstride)
+        h1 = bld.conv(a1, W[p + ".conv1.2.w"], cout, bias=W[p + ".conv1.2.b"], temb=temb[:, o:o + cout], temb_stride=tstride,
+                      want_stats=True)
         bld.free(a1)
         a2 = bld.groupnorm(h1, W[p + ".conv2.0.g"], W[p + ".conv2.0.b"], 32, act="silu")
         bld.free(h1)
@@ -290,7 +291,7 @@ def emit_unet_forward(bld, model, W, x_nchw, t_dev, eps_out):
         else:
             assert x2 is None
             sc = x1
-        y = bld.conv(a2, W[p + ".conv2.3.w"], cout, bias=W[p + ".conv2.3.b"], residual=sc)
+        y = bld.conv(a2, W[p + ".conv2.3.w"], cout, bias=W[p + ".conv2.3.b"], residual=sc, want_stats=True)
         bld.free(a2)
         if sc is not x1:
             bld.free(sc)
@@ -304,7 +305,7 @@ def emit_unet_forward(bld, model, W, x_nchw, t_dev, eps_out):
         # per head the 3d output channels are [q | k | v] (reshape + chunk, diff_model.py:120)
         o = bld.attention(qkv, heads, d, 0, d, 2 * d, 3 * d)
         bld.free(qkv)
-        y = bld.conv(o, W[p + ".proj.w"], ch, bias=W[p + ".proj.b"], residual=x, ksize=1, pad=0)
+        y = bld.conv(o, W[p + ".proj.w"], ch, bias=W[p + ".proj.b"], residual=x, ksize=1, pad=0, want_stats=True)
         bld.free(o)
         return y
 
@@ -318,9 +319,9 @@ def emit_unet_forward(bld, model, W, x_nchw, t_dev, eps_out):
             elif kind == "attn":
                 new = attn_block(p, cin, h)
             elif kind == "down":
-                new = bld.conv(h, W[p + ".op.w"], cout, bias=W[p + ".op.b"], stride=2)
+                new = bld.conv(h, W[p + ".op.w"], cout, bias=W[p + ".op.b"], stride=2, want_stats=True)
             elif kind == "up":
-                new = bld.conv(h, W[p + ".conv.w"], cout, bias=W[p + ".conv.b"], upsample=True)
+                new = bld.conv(h, W[p + ".conv.w"], cout, bias=W[p + ".conv.b"], upsample=True, want_stats=True)
             if h is not None and not any(h is s for s in hs):
                 bld.free(h)
             h = new

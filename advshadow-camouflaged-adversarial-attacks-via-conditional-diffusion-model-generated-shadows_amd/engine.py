@@ -113,6 +113,7 @@ class Builder:
         self.arena = Arena(device)
         self.plan = Plan(stream)
         self._base = {}
+        self.stats = {}               # data_ptr of a conv output -> (stats tensor, row blocks per image)
         nb = self.lib.advs_groupnorm_scratch_bytes(batch, 64)
         self.gn_scratch = torch.empty(nb, dtype=torch.uint8, device=device)
 
@@ -132,20 +133,31 @@ class Builder:
         base = self._base.pop(t.data_ptr(), None)
         if base is not None:
             self.arena.release(base)
+        st = self.stats.pop(t.data_ptr(), None)
+        if st is not None:
+            self.free(st[0])
 
     # ---- ops (activations are NHWC tensors [B,H,W,C] of the compute dtype)
     def conv(self, x1, w, cout, *, x2=None, bias=None, temb=None, temb_stride=0, residual=None,
-             ksize=3, stride=1, pad=1, upsample=False, act=None, out=None, tile=0):
+             ksize=3, stride=1, pad=1, upsample=False, act=None, out=None, tile=0, want_stats=False):
         B, H, W, C1 = x1.shape
         C2 = 0 if x2 is None else x2.shape[3]
         HL, WL = (H * 2, W * 2) if upsample else (H, W)
         Ho = (HL + 2 * pad - ksize) // stride + 1
         Wo = (WL + 2 * pad - ksize) // stride + 1
         y = out if out is not None else self.buf((B, Ho, Wo, cout))
+        stats = None
+        if want_stats:
+            # per-channel (sum, sumsq) per row block from the epilogue, for the GroupNorm that reads y
+            tile = tile or self.lib.advs_conv_pick_tile(B * Ho * Wo, cout)
+            rows = self.lib.advs_conv_tile_rows(tile)
+            if rows > 0 and (Ho * Wo) % rows == 0:
+                stats = self.buf((B * Ho * Wo // rows, cout, 2), torch.float32)
+                self.stats[y.data_ptr()] = (stats, Ho * Wo // rows)
         a = ConvArgs(ptr(x1), ptr(x2), ptr(w), ptr(bias), ptr(temb), ptr(residual), ptr(y),
                      B, H, W, C1, C2, cout, ksize, stride, pad, 1 if upsample else 0,
-                     ACT[act], self.dt, temb_stride, tile)
-        self.plan.add(self.lib.advs_conv2d, C.byref(a), keep=(a, x1, x2, w, bias, temb, residual, y))
+                     ACT[act], self.dt, temb_stride, tile, ptr(stats))
+        self.plan.add(self.lib.advs_conv2d, C.byref(a), keep=(a, x1, x2, w, bias, temb, residual, y, stats))
         return y
 
     def conv_first(self, x_nchw, w, bias, cout):
@@ -165,6 +177,14 @@ class Builder:
         B, H, W, C1 = x.shape
         C2 = 0 if x2 is None else x2.shape[3]
         y = self.buf((B, H, W, C1 + C2))
+        s1 = self.stats.get(x.data_ptr())
+        s2 = self.stats.get(x2.data_ptr()) if x2 is not None else None
+        if s1 is not None and (x2 is None or s2 is not None):
+            self.plan.add(self.lib.advs_groupnorm_stats, ptr(x), ptr(x2), ptr(s1[0]), s1[1],
+                          ptr(s2[0]) if s2 else 0, s2[1] if s2 else 0, ptr(gamma), ptr(beta), ptr(residual),
+                          ptr(chan_add), chan_add_stride, ptr(y), ptr(self.gn_scratch), B, H * W, C1, C2, groups,
+                          ACT[act], self.dt, keep=(x, x2, s1, s2, gamma, beta, residual, chan_add, y))
+            return y
         self.plan.add(self.lib.advs_groupnorm, ptr(x), ptr(x2), ptr(gamma), ptr(beta), ptr(residual), ptr(chan_add),
                       chan_add_stride, ptr(y), ptr(self.gn_scratch), B, H * W, C1, C2, groups, ACT[act], self.dt,
                       keep=(x, x2, gamma, beta, residual, chan_add, y))

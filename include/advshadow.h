@@ -63,9 +63,14 @@ typedef struct advs_conv_args {
     int act, dtype;
     int temb_stride;                    /* floats between consecutive samples' temb rows    */
     int tile;                           /* 0 = choose; 1: 128x128, 2|3: 256x128, 4: 256x256  */
+    float* stats;                       /* NULL, or [ceil(M/rows)][cout][2]: per row block (rows =
+                                           advs_conv_tile_rows(tile), must divide ho*wo) and channel the
+                                           (sum, sum of squares) of y as stored -> advs_groupnorm_stats */
 } advs_conv_args;
 int advs_conv2d(const advs_conv_args* a, void* stream);
 int advs_conv_set_tile(int tile);       /* tuning hook: non-zero overrides every call's tile  */
+int advs_conv_pick_tile(long long m, int cout);   /* the tile id tile = 0 resolves to for an m x cout output */
+int advs_conv_tile_rows(int tile);      /* row-block height (rows per stats entry) of a tile id */
 
 /* First conv: NCHW f32 image (cin <= 4) -> NHWC `dtype`, 3x3 pad 1 (diff_model.py:192;
  * model/modules/conv.py:38 for inc).  w is the torch OIHW f32 weight.                      */
@@ -90,6 +95,15 @@ int advs_groupnorm(const void* x, const void* x2, const float* gamma, const floa
                    const void* residual_in, const float* chan_add, int chan_add_stride, void* y,
                    void* partials, int b, int hw, int c, int c2, int groups, int act, int dtype,
                    void* stream);
+
+/* GroupNorm whose statistics come from the producing convs' epilogues (advs_conv_args.stats) instead
+ * of a pass over x: stats1/stats2 are those arrays, row_blocks_per_image = ho*wo / tile rows.
+ * scratch: b*groups*2 floats.                                                                    */
+int advs_groupnorm_stats(const void* x, const void* x2, const float* stats1, int row_blocks_per_image1,
+                         const float* stats2, int row_blocks_per_image2, const float* gamma,
+                         const float* beta, const void* residual_in, const float* chan_add,
+                         int chan_add_stride, void* y, void* scratch, int b, int hw, int c, int c2,
+                         int groups, int act, int dtype, void* stream);
 
 /* ---- resampling / token norm of the class-conditional UNet -----------------------------
  * MaxPool2d(2) (model/modules/block.py:27); y is [b][h/2][w/2][c].                          */

@@ -346,3 +346,30 @@ def test_groupnorm_chan_add(dt):
     op.go()
     err = (nchw(y) - ref).abs().max().item()
     assert err < tol(dt, 2e-5, 3e-2), err
+
+
+# ------------------------------------------------------------------------------ GN statistics from the conv epilogue
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("tiles", [(1, 1), (4, 1), (1, 4), (3, 5)])
+def test_groupnorm_with_epilogue_stats(dt, tiles):
+    """conv(+stats) x2 -> GroupNorm(32) over their concat (groups of 12 straddle the sources) must equal
+    the unfused path; statistics come from [row block][channel] partials written by the epilogues."""
+    B, H, W = 2, 16, 16
+    xa, xb = rnd(B, 64, H, W, seed=41), rnd(B, 64, H, W, seed=42)
+    wa, wb = rnd(256, 64, 3, 3, seed=43, scale=0.05), rnd(128, 64, 1, 1, seed=44, scale=0.2)
+    gamma, beta = rnd(384, seed=45) * 0.3 + 1, rnd(384, seed=46) * 0.1
+    r = (lambda t: bf16_round(t)) if dt == "bf16" else (lambda t: t)
+    ya = r(F.conv2d(r(xa), r(wa), padding=1))
+    yb = r(F.relu(F.conv2d(r(xb), r(wb))))
+    ref = F.silu(F.group_norm(torch.cat([ya, yb], 1), 32, gamma, beta, eps=1e-5))
+    op = OneOp(dt, B)
+    code = dtype_code(dt)
+    ca = op.b.conv(nhwc(xa, dt), pack_conv_weight(wa.to(dev()), code), 256, tile=tiles[0], want_stats=True)
+    cb = op.b.conv(nhwc(xb, dt), pack_conv_weight(wb.to(dev()), code), 128, ksize=1, pad=0, act="relu", tile=tiles[1],
+                   want_stats=True)
+    assert ca.data_ptr() in op.b.stats and cb.data_ptr() in op.b.stats
+    y = op.b.groupnorm(ca, gamma.to(dev()), beta.to(dev()), 32, act="silu", x2=cb)
+    assert op.b.plan.ops[-1][0].__name__ == "advs_groupnorm_stats"
+    op.go()
+    err = (nchw(y) - ref).abs().max().item()
+    assert err < tol(dt, 3e-5, 4e-2), err
