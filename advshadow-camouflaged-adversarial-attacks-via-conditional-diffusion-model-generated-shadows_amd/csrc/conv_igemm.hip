@@ -79,7 +79,7 @@ template <> struct Mma<float> {
     }
 };
 
-template <typename T, int BM, int BN, int WM, int WN, int NSTAGE>
+template <typename T, int BM, int BN, int WM, int WN, int NSTAGE, bool ILV>
 __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
 conv_igemm_kernel(const ConvKP p) {
     constexpr int ESZ = Mma<T>::ESZ;
@@ -143,13 +143,18 @@ conv_igemm_kernel(const ConvKP p) {
     int kr = 0, ks = 0, c0 = 0;
     const int nk = p.K / BKE;
 
-    auto stage = [&](int buf, int kt) {
-        char* la = smem + buf * STAGE;
-        char* lb = la + A_BYTES;
-        const bool first = c0 < p.C1;
+    // Staging of one K-slab, split so the main loop can spread the DMA issue over its k-steps:
+    // stage_begin (uniform bookkeeping + per-row offsets on a new (tap, source) segment), then AR+BR
+    // loads issued by stage_part(q) for q = 0..3, then stage_end (advance the cursor).
+    bool st_first = true;
+    unsigned st_soff = 0, st_woff = 0;
+    char* st_la = smem;
+    auto stage_begin = [&](int buf, int kt) {
+        st_la = smem + buf * STAGE;
+        st_first = c0 < p.C1;
         if (c0 == 0 || c0 == p.C1) {
             // new (tap, source) segment: per-row byte offset of the source pixel, or out of range
-            const unsigned cs = (unsigned)(first ? p.C1 : p.C2) * ESZ;
+            const unsigned cs = (unsigned)(st_first ? p.C1 : p.C2) * ESZ;
 #pragma unroll
             for (int j = 0; j < AR; ++j) {
                 const int iy = a_iy[j] + kr, ix = a_ix[j] + ks;
@@ -158,19 +163,30 @@ conv_igemm_kernel(const ConvKP p) {
                 a_voff[j] = ok ? pix * cs + a_csw[j] : OOB_OFFSET;
             }
         }
-        const unsigned soff = (unsigned)(first ? c0 : c0 - p.C1) * ESZ;
-        if (first) {
+        st_soff = (unsigned)(st_first ? c0 : c0 - p.C1) * ESZ;
+        st_woff = (unsigned)kt * SLAB;
+    };
+    auto stage_part = [&](int q) {                        // q-th quarter of the slab's loads
+        char* lb = st_la + A_BYTES;
 #pragma unroll
-            for (int j = 0; j < AR; ++j) blds16(rs1, a_voff[j], soff, la + (wave * AR + j) * 1024);
-        } else {
+        for (int j = 0; j < AR; ++j)
+            if (j * 4 / AR == q) {
+                if (st_first) blds16(rs1, a_voff[j], st_soff, st_la + (wave * AR + j) * 1024);
+                else blds16(rs2, a_voff[j], st_soff, st_la + (wave * AR + j) * 1024);
+            }
 #pragma unroll
-            for (int j = 0; j < AR; ++j) blds16(rs2, a_voff[j], soff, la + (wave * AR + j) * 1024);
-        }
-        const unsigned woff = (unsigned)kt * SLAB;
-#pragma unroll
-        for (int j = 0; j < BR; ++j) blds16(rsw, b_voff[j], woff, lb + (wave * BR + j) * 1024);
+        for (int j = 0; j < BR; ++j)
+            if (j * 4 / BR == q) blds16(rsw, b_voff[j], st_woff, lb + (wave * BR + j) * 1024);
+    };
+    auto stage_end = [&]() {
         c0 += BKE;
         if (c0 == Cin) { c0 = 0; if (++ks == p.R) { ks = 0; ++kr; } }
+    };
+    auto stage = [&](int buf, int kt) {
+        stage_begin(buf, kt);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) stage_part(q);
+        stage_end();
     };
 
     f32x16 acc[TM][TN];
@@ -196,7 +212,7 @@ conv_igemm_kernel(const ConvKP p) {
         b_off[j] = rb * SLAB; b_sw[j] = (rb >> 1) & 7;
     }
 
-    if constexpr (NSTAGE == 2) {
+    if constexpr (NSTAGE == 2 && !ILV) {
         // two buffers, two barriers per slab: slab kt+1 is in flight while slab kt is consumed
         stage(0, 0);
         for (int kt = 0; kt < nk; ++kt) {
@@ -222,6 +238,48 @@ conv_igemm_kernel(const ConvKP p) {
 #pragma unroll
                     for (int j = 0; j < TN; ++j) Mma<T>::run(af[i], bf[j], acc[i][j]);
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this wave's LDS reads retired ...
+            __builtin_amdgcn_s_barrier();                            // ... before anyone restages buf
+        }
+    } else if constexpr (NSTAGE == 2) {
+        // two buffers, two barriers per slab.  The loads of slab kt+1 are issued a quarter at a time
+        // BETWEEN the MFMA groups of slab kt (their buffer was released by the barrier that ended
+        // iteration kt-1), and the fragments of k-step s+1 are read while step s multiplies, so the
+        // wave's DMA issue and LDS latency hide behind its own matrix work.
+        stage(0, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // slab kt (issued during kt-1) landed
+            __builtin_amdgcn_s_barrier();
+            const char* la = smem + buf * STAGE;
+            const char* lb = la + A_BYTES;
+            const bool more = kt + 1 < nk;
+            if (more) stage_begin(buf ^ 1, kt + 1);
+            u32x4 af[2][TM], bf[2][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[0][i] = *(const u32x4*)(la + a_off[i] + (((0 + lh) ^ a_sw[i]) << 4));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[0][j] = *(const u32x4*)(lb + b_off[j] + (((0 + lh) ^ b_sw[j]) << 4));
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int cur = s & 1, nxt = cur ^ 1;
+                if (s < 3) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        af[nxt][i] = *(const u32x4*)(la + a_off[i] + (((2 * (s + 1) + lh) ^ a_sw[i]) << 4));
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        bf[nxt][j] = *(const u32x4*)(lb + b_off[j] + (((2 * (s + 1) + lh) ^ b_sw[j]) << 4));
+                }
+                if (more) stage_part(s);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) Mma<T>::run(af[cur][i], bf[cur][j], acc[i][j]);
+                __builtin_amdgcn_s_setprio(0);
+            }
+            if (more) stage_end();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this wave's LDS reads retired ...
             __builtin_amdgcn_s_barrier();                            // ... before anyone restages buf
         }
@@ -340,18 +398,18 @@ conv_igemm_kernel(const ConvKP p) {
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int NSTAGE = 2>
+template <typename T, int BM, int BN, int WM, int WN, int NSTAGE = 2, bool ILV = false>
 static int conv_launch(ConvKP& p, hipStream_t st) {
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
     constexpr int lds = NSTAGE * (BM + BN) * SLAB;
     static bool attr_set = false;
     if (!attr_set) {
-        ADVS_HIP(hipFuncSetAttribute((const void*)conv_igemm_kernel<T, BM, BN, WM, WN, NSTAGE>,
+        ADVS_HIP(hipFuncSetAttribute((const void*)conv_igemm_kernel<T, BM, BN, WM, WN, NSTAGE, ILV>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
     p.nMt = cdiv(p.M, BM); p.nNt = cdiv(p.Cout, BN);
-    conv_igemm_kernel<T, BM, BN, WM, WN, NSTAGE><<<p.nMt * p.nNt, NT, lds, st>>>(p);
+    conv_igemm_kernel<T, BM, BN, WM, WN, NSTAGE, ILV><<<p.nMt * p.nNt, NT, lds, st>>>(p);
     ADVS_CHECK_LAUNCH("conv_igemm");
     return ADVS_OK;
 }
@@ -362,10 +420,14 @@ template <typename T>
 static int conv_dispatch(ConvKP& p, int tile, hipStream_t st) {
     if (tile == 0) tile = pick_tile(p.M, p.Cout);
     switch (tile) {
-        case 1: return conv_launch<T, 128, 128, 64, 64>(p, st);
-        case 2: return conv_launch<T, 256, 128, 64, 64>(p, st);
-        case 3: return conv_launch<T, 256, 128, 128, 64>(p, st);
-        case 4: return conv_launch<T, 256, 256, 128, 64>(p, st);
+        // ILV (DMA issue spread between the MFMA groups) pays when both waves of a SIMD belong to one
+        // workgroup and so run in lockstep (8-wave tiles); with two 4-wave workgroups per CU the plain
+        // loop is faster because the workgroups already interleave each other (tools/tune_conv.py).
+        case 1: return conv_launch<T, 128, 128, 64, 64, 2, false>(p, st);
+        case 2: return conv_launch<T, 256, 128, 64, 64, 2, true>(p, st);
+        case 3: return conv_launch<T, 256, 128, 128, 64, 2, true>(p, st);
+        case 4: return conv_launch<T, 256, 256, 128, 64, 2, true>(p, st);
+        case 8: return conv_launch<T, 128, 128, 64, 64, 2, true>(p, st);
         case 5: return conv_launch<T, 256, 128, 64, 64, 3>(p, st);
         case 6: return conv_launch<T, 128, 128, 64, 64, 3>(p, st);
         case 7: return conv_launch<T, 256, 128, 128, 64, 3>(p, st);
@@ -386,7 +448,7 @@ static int pick_tile(long long M, int cout) {
 /* tile id advs_conv2d would choose for an M x cout output, and the row-block height (WM) of a tile id */
 extern "C" int advs_conv_pick_tile(long long m, int cout) { return g_tile_override ? g_tile_override : pick_tile(m, cout); }
 extern "C" int advs_conv_tile_rows(int tile) {
-    switch (tile) { case 1: case 2: case 5: case 6: return 64; case 3: case 4: case 7: return 128; default: return 0; }
+    switch (tile) { case 1: case 2: case 5: case 6: case 8: return 64; case 3: case 4: case 7: return 128; default: return 0; }
 }
 
 extern "C" int advs_conv2d(const advs_conv_args* a, void* stream) {
@@ -427,6 +489,8 @@ extern "C" int advs_conv2d(const advs_conv_args* a, void* stream) {
         const int wm = advs_conv_tile_rows(tile ? tile : pick_tile(p.M, p.Cout));
         ADVS_REQUIRE(wm > 0 && (p.Ho * p.Wo) % wm == 0, "conv2d: stats need Ho*Wo (%d) to be a multiple of the tile's row block (%d)",
                      p.Ho * p.Wo, wm);
+        if (g_tile_override && a->stats_rows != wm) p.stats = nullptr;   // tuning runs: buffer sized for another tile
+        else ADVS_REQUIRE(a->stats_rows == wm, "conv2d: stats buffer sized for %d-row blocks but the tile uses %d", a->stats_rows, wm);
     }
     if (a->dtype == ADVS_BF16) return conv_dispatch<BF16>(p, tile, (hipStream_t)stream);
     return conv_dispatch<float>(p, tile, (hipStream_t)stream);

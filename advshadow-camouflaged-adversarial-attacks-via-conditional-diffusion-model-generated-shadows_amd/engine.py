@@ -146,7 +146,7 @@ class Builder:
         Ho = (HL + 2 * pad - ksize) // stride + 1
         Wo = (WL + 2 * pad - ksize) // stride + 1
         y = out if out is not None else self.buf((B, Ho, Wo, cout))
-        stats = None
+        stats, rows = None, 0
         if want_stats:
             # per-channel (sum, sumsq) per row block from the epilogue, for the GroupNorm that reads y
             tile = tile or self.lib.advs_conv_pick_tile(B * Ho * Wo, cout)
@@ -156,7 +156,7 @@ class Builder:
                 self.stats[y.data_ptr()] = (stats, Ho * Wo // rows)
         a = ConvArgs(ptr(x1), ptr(x2), ptr(w), ptr(bias), ptr(temb), ptr(residual), ptr(y),
                      B, H, W, C1, C2, cout, ksize, stride, pad, 1 if upsample else 0,
-                     ACT[act], self.dt, temb_stride, tile, ptr(stats))
+                     ACT[act], self.dt, temb_stride, tile, ptr(stats), rows if stats is not None else 0)
         self.plan.add(self.lib.advs_conv2d, C.byref(a), keep=(a, x1, x2, w, bias, temb, residual, y, stats))
         return y
 

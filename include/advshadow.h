@@ -66,6 +66,7 @@ typedef struct advs_conv_args {
     float* stats;                       /* NULL, or [ceil(M/rows)][cout][2]: per row block (rows =
                                            advs_conv_tile_rows(tile), must divide ho*wo) and channel the
                                            (sum, sum of squares) of y as stored -> advs_groupnorm_stats */
+    int stats_rows;                     /* the row-block height `stats` was sized for (checked)          */
 } advs_conv_args;
 int advs_conv2d(const advs_conv_args* a, void* stream);
 int advs_conv_set_tile(int tile);       /* tuning hook: non-zero overrides every call's tile  */
