@@ -428,6 +428,7 @@ static int conv_dispatch(ConvKP& p, int tile, hipStream_t st) {
         case 3: return conv_launch<T, 256, 128, 128, 64, 2, true>(p, st);
         case 4: return conv_launch<T, 256, 256, 128, 64, 2, true>(p, st);
         case 8: return conv_launch<T, 128, 128, 64, 64, 2, true>(p, st);
+        case 9: return conv_launch<T, 512, 128, 128, 64, 2, true>(p, st);
         case 5: return conv_launch<T, 256, 128, 64, 64, 3>(p, st);
         case 6: return conv_launch<T, 128, 128, 64, 64, 3>(p, st);
         case 7: return conv_launch<T, 256, 128, 128, 64, 3>(p, st);
@@ -448,7 +449,7 @@ static int pick_tile(long long M, int cout) {
 /* tile id advs_conv2d would choose for an M x cout output, and the row-block height (WM) of a tile id */
 extern "C" int advs_conv_pick_tile(long long m, int cout) { return g_tile_override ? g_tile_override : pick_tile(m, cout); }
 extern "C" int advs_conv_tile_rows(int tile) {
-    switch (tile) { case 1: case 2: case 5: case 6: case 8: return 64; case 3: case 4: case 7: return 128; default: return 0; }
+    switch (tile) { case 1: case 2: case 5: case 6: case 8: return 64; case 3: case 4: case 7: case 9: return 128; default: return 0; }
 }
 
 extern "C" int advs_conv2d(const advs_conv_args* a, void* stream) {

@@ -171,37 +171,49 @@ gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ x2, int C1, const
 }
 
 // Statistics already emitted by the producing conv epilogues (advs_conv_args.stats): per source a
-// [row blocks][C][2] array of per-channel (sum, sum of squares).  One workgroup per (group, sample)
-// folds them in a fixed order and writes (mean, rstd).
+// [row blocks][C][2] array of per-channel (sum, sum of squares).  gn_stats_fold_kernel turns a slice
+// of one sample's row blocks into per-group partial sums in the SAME layout gn_partial_kernel writes
+// (partials[b][chunk][g][2]), so gn_apply_kernel combines them exactly as in the unfused path.
+// Reads are channel-contiguous (a wave covers 512 consecutive bytes); order of summation is fixed.
+#define GNF_MAXC 1024
 __global__ void __launch_bounds__(256)
-gn_finalize_kernel(const float* __restrict__ st1, int rbpi1, int C1, const float* __restrict__ st2, int rbpi2, int C2,
-                   float* __restrict__ meanrstd, int HW, int G) {
-    __shared__ double rs[256], rq[256];
-    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    const int C = C1 + C2, cpg = C / G;
-    double s = 0.0, q = 0.0;
-    for (int cc = 0; cc < cpg; ++cc) {
-        const int c = g * cpg + cc;
-        const bool in1 = c < C1;
-        const float* st = in1 ? st1 : st2;
-        const int rb = in1 ? rbpi1 : rbpi2, Cs = in1 ? C1 : C2, cl = in1 ? c : c - C1;
-        for (int r = tid; r < rb; r += 256) {
-            const float* e = st + (((size_t)b * rb + r) * Cs + cl) * 2;
-            s += (double)e[0]; q += (double)e[1];
+gn_stats_fold_kernel(const float* __restrict__ st1, int rbpi1, int C1, const float* __restrict__ st2, int rbpi2, int C2,
+                     float* __restrict__ partials, int G, int nsplit) {
+    __shared__ double tmp[4 * 256 * 2];           // [row lane][channel in chunk][2]
+    __shared__ double chs[GNF_MAXC * 2];          // per concatenated channel (sum, sumsq)
+    const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const int C = C1 + C2;
+    for (int src = 0; src < 2; ++src) {
+        const float* st = src ? st2 : st1;
+        const int Cs = src ? C2 : C1, rbpi = src ? rbpi2 : rbpi1, cbase = src ? C1 : 0;
+        if (Cs == 0) continue;
+        const int per = (rbpi + nsplit - 1) / nsplit;
+        const int r0 = chunk * per, r1 = min(rbpi, r0 + per);
+        const int rows_par = Cs < 256 ? 256 / Cs : 1;
+        const int rl = Cs < 256 ? tid / Cs : 0, cl = Cs < 256 ? tid - rl * Cs : tid;
+        for (int c0 = 0; c0 < Cs; c0 += 256) {
+            const int c = c0 + cl;
+            double s = 0.0, q = 0.0;
+            if (c < Cs && rl < rows_par)
+                for (int r = r0 + rl; r < r1; r += rows_par) {
+                    const float2 e = *(const float2*)(st + (((size_t)b * rbpi + r) * Cs + c) * 2);
+                    s += (double)e.x; q += (double)e.y;
+                }
+            tmp[(rl * 256 + cl) * 2] = s; tmp[(rl * 256 + cl) * 2 + 1] = q;
+            __syncthreads();
+            if (rl == 0 && c < Cs) {
+                for (int l = 1; l < rows_par; ++l) { s += tmp[(l * 256 + cl) * 2]; q += tmp[(l * 256 + cl) * 2 + 1]; }
+                chs[(cbase + c) * 2] = s; chs[(cbase + c) * 2 + 1] = q;
+            }
+            __syncthreads();
         }
     }
-    rs[tid] = s; rq[tid] = q;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (tid < o) { rs[tid] += rs[tid + o]; rq[tid] += rq[tid + o]; }
-        __syncthreads();
-    }
-    if (tid == 0) {
-        const double n = (double)HW * cpg, mean = rs[0] / n;
-        double var = rq[0] / n - mean * mean;
-        if (var < 0.0) var = 0.0;
-        meanrstd[((size_t)b * G + g) * 2] = (float)mean;
-        meanrstd[((size_t)b * G + g) * 2 + 1] = (float)(1.0 / sqrt(var + 1e-5));
+    const int cpg = C / G;
+    for (int g = tid; g < G; g += 256) {
+        double s = 0.0, q = 0.0;
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) { s += chs[c * 2]; q += chs[c * 2 + 1]; }
+        float* out = partials + (((size_t)b * nsplit + chunk) * G + g) * 2;
+        out[0] = (float)s; out[1] = (float)q;
     }
 }
 
@@ -215,9 +227,13 @@ static int gn_launch(const void* x, const void* x2, int c1, const float* gamma, 
     const float* meanrstd = nullptr;
     int nchunk = 1;
     if (st1) {
-        gn_finalize_kernel<<<dim3(groups, b), 256, 0, st>>>(st1, rbpi1, c1, st2, rbpi2, c - c1, partials, hw, groups);
-        ADVS_CHECK_LAUNCH("gn_finalize");
-        meanrstd = partials;
+        const int rbmax = rbpi1 > rbpi2 ? rbpi1 : rbpi2;
+        nchunk = 256 / b;                                   // enough workgroups to cover the chip
+        if (nchunk > rbmax / 8) nchunk = rbmax / 8;
+        if (nchunk > GN_MAX_CHUNKS) nchunk = GN_MAX_CHUNKS;
+        if (nchunk < 1) nchunk = 1;
+        gn_stats_fold_kernel<<<dim3(nchunk, b), 256, 0, st>>>(st1, rbpi1, c1, st2, rbpi2, c - c1, partials, groups, nchunk);
+        ADVS_CHECK_LAUNCH("gn_stats_fold");
     } else {
     // enough chunks to fill 256 CUs several times over, but >= 4 pixels per lane per chunk
     nchunk = 2048 / b;
@@ -272,7 +288,7 @@ extern "C" int advs_groupnorm_stats(const void* x, const void* x2, const float* 
     const int c = c1 + c2;
     ADVS_REQUIRE(b > 0 && hw > 0 && groups > 0 && groups <= 64 && c % groups == 0, "groupnorm_stats: bad shape");
     const int vec = dtype == ADVS_BF16 ? 8 : 4;
-    ADVS_REQUIRE(c1 % vec == 0 && c2 % vec == 0 && c / vec <= GN_THREADS, "groupnorm_stats: c=%d+%d unsupported", c1, c2);
+    ADVS_REQUIRE(c1 % vec == 0 && c2 % vec == 0 && c / vec <= GN_THREADS && c <= GNF_MAXC, "groupnorm_stats: c=%d+%d unsupported", c1, c2);
     if (dtype == ADVS_BF16)
         return gn_launch<BF16>(x, x2, c1, gamma, beta, residual_in, y, (float*)scratch, b, hw, c, groups, act, chan_add,
                                chan_add_stride, (hipStream_t)stream, stats1, row_blocks_per_image1, stats2, row_blocks_per_image2);
