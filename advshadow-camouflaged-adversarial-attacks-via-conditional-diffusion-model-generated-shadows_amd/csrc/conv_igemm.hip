@@ -19,6 +19,10 @@
 // temb / residual are read and y is written as 16-byte vectors along the channel axis
 // (whole 128-byte lines), instead of one element per lane.
 //
+// An optional EXTRA operand (again up to two concatenated sources, [B][Ho][Wo][E]) is appended to K as
+// a 1x1 stride-1 tap: y = conv_RxR(x) + conv_1x1(e) in ONE launch -- the residual block's
+// `conv2(h) + shortcut(x)` (diff_model.py:102-103) without writing and re-reading the shortcut.
+//
 // Optionally the epilogue also emits, per WM-row block and channel, the sum and sum of squares of the
 // stored values: the GroupNorm that consumes y then needs no statistics pass over the tensor.
 //
@@ -41,6 +45,8 @@ struct FastDiv {
 
 struct ConvKP {
     const char* x1; const char* x2; const char* w;
+    const char* e1; const char* e2;   // extra 1x1 operand (two concat sources) appended to K, or null
+    int E1, E2; unsigned e1_bytes, e2_bytes;
     const float* bias; const float* temb; const char* res; char* y;
     float* stats;                // [ceil(M/WM)][Cout][2] per-channel (sum, sum of squares) of y, or null
     unsigned x1_bytes, x2_bytes, w_bytes;
@@ -113,7 +119,7 @@ conv_igemm_kernel(const ConvKP p) {
     const int Cin = p.C1 + p.C2;
     const int HL = p.H << p.ups, WL = p.W << p.ups;
     const int chunk = lane & 7;
-    int a_b[AR], a_iy[AR], a_ix[AR];
+    int a_b[AR], a_iy[AR], a_ix[AR], a_m[AR];
     unsigned a_csw[AR], a_voff[AR], b_voff[BR];
 #pragma unroll
     for (int j = 0; j < AR; ++j) {
@@ -124,9 +130,9 @@ conv_igemm_kernel(const ConvKP p) {
         if (m < p.M) {
             const int b = (int)p.dHoWo.div((unsigned)m), rem = m - b * HoWo;
             const int oy = (int)p.dWo.div((unsigned)rem), ox = rem - oy * p.Wo;
-            a_b[j] = b; a_iy[j] = oy * p.stride - p.pad; a_ix[j] = ox * p.stride - p.pad;
+            a_b[j] = b; a_iy[j] = oy * p.stride - p.pad; a_ix[j] = ox * p.stride - p.pad; a_m[j] = m;
         } else {
-            a_b[j] = 0; a_iy[j] = -0x40000000; a_ix[j] = 0;      // always out of the image
+            a_b[j] = 0; a_iy[j] = -0x40000000; a_ix[j] = 0; a_m[j] = -1;      // always out of the image
         }
     }
 #pragma unroll
@@ -138,6 +144,8 @@ conv_igemm_kernel(const ConvKP p) {
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x1, 0, p.x1_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x2 ? p.x2 : p.x1), 0, p.x2_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rse1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.e1 ? p.e1 : p.x1), 0, p.e1_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rse2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.e2 ? p.e2 : p.x1), 0, p.e2_bytes, 0x00020000);
 
     // K-slab cursor (uniform): tap (r, s) and channel offset c0 inside the concatenated input
     int kr = 0, ks = 0, c0 = 0;
@@ -146,24 +154,37 @@ conv_igemm_kernel(const ConvKP p) {
     // Staging of one K-slab, split so the main loop can spread the DMA issue over its k-steps:
     // stage_begin (uniform bookkeeping + per-row offsets on a new (tap, source) segment), then AR+BR
     // loads issued by stage_part(q) for q = 0..3, then stage_end (advance the cursor).
-    bool st_first = true;
+    int st_sel = 0;                                       // 0: x1, 1: x2, 2: e1, 3: e2
     unsigned st_soff = 0, st_woff = 0;
     char* st_la = smem;
     auto stage_begin = [&](int buf, int kt) {
         st_la = smem + buf * STAGE;
-        st_first = c0 < p.C1;
-        if (c0 == 0 || c0 == p.C1) {
-            // new (tap, source) segment: per-row byte offset of the source pixel, or out of range
-            const unsigned cs = (unsigned)(st_first ? p.C1 : p.C2) * ESZ;
+        if (kr < p.R) {
+            const bool first = c0 < p.C1;
+            st_sel = first ? 0 : 1;
+            if (c0 == 0 || c0 == p.C1) {
+                // new (tap, source) segment: per-row byte offset of the source pixel, or out of range
+                const unsigned cs = (unsigned)(first ? p.C1 : p.C2) * ESZ;
 #pragma unroll
-            for (int j = 0; j < AR; ++j) {
-                const int iy = a_iy[j] + kr, ix = a_ix[j] + ks;
-                const bool ok = (unsigned)iy < (unsigned)HL && (unsigned)ix < (unsigned)WL;
-                const unsigned pix = (unsigned)((a_b[j] * p.H + (iy >> p.ups)) * p.W + (ix >> p.ups));
-                a_voff[j] = ok ? pix * cs + a_csw[j] : OOB_OFFSET;
+                for (int j = 0; j < AR; ++j) {
+                    const int iy = a_iy[j] + kr, ix = a_ix[j] + ks;
+                    const bool ok = (unsigned)iy < (unsigned)HL && (unsigned)ix < (unsigned)WL;
+                    const unsigned pix = (unsigned)((a_b[j] * p.H + (iy >> p.ups)) * p.W + (ix >> p.ups));
+                    a_voff[j] = ok ? pix * cs + a_csw[j] : OOB_OFFSET;
+                }
             }
+            st_soff = (unsigned)(first ? c0 : c0 - p.C1) * ESZ;
+        } else {
+            // extra operand: the output pixel itself, channels [0, E1) of e1 then [0, E2) of e2
+            const bool first = c0 < p.E1;
+            st_sel = first ? 2 : 3;
+            if (c0 == 0 || c0 == p.E1) {
+                const unsigned cs = (unsigned)(first ? p.E1 : p.E2) * ESZ;
+#pragma unroll
+                for (int j = 0; j < AR; ++j) a_voff[j] = a_m[j] >= 0 ? (unsigned)a_m[j] * cs + a_csw[j] : OOB_OFFSET;
+            }
+            st_soff = (unsigned)(first ? c0 : c0 - p.E1) * ESZ;
         }
-        st_soff = (unsigned)(st_first ? c0 : c0 - p.C1) * ESZ;
         st_woff = (unsigned)kt * SLAB;
     };
     auto stage_part = [&](int q) {                        // q-th quarter of the slab's loads
@@ -171,8 +192,11 @@ conv_igemm_kernel(const ConvKP p) {
 #pragma unroll
         for (int j = 0; j < AR; ++j)
             if (j * 4 / AR == q) {
-                if (st_first) blds16(rs1, a_voff[j], st_soff, st_la + (wave * AR + j) * 1024);
-                else blds16(rs2, a_voff[j], st_soff, st_la + (wave * AR + j) * 1024);
+                char* dst = st_la + (wave * AR + j) * 1024;
+                if (st_sel == 0) blds16(rs1, a_voff[j], st_soff, dst);
+                else if (st_sel == 1) blds16(rs2, a_voff[j], st_soff, dst);
+                else if (st_sel == 2) blds16(rse1, a_voff[j], st_soff, dst);
+                else blds16(rse2, a_voff[j], st_soff, dst);
             }
 #pragma unroll
         for (int j = 0; j < BR; ++j)
@@ -180,7 +204,7 @@ conv_igemm_kernel(const ConvKP p) {
     };
     auto stage_end = [&]() {
         c0 += BKE;
-        if (c0 == Cin) { c0 = 0; if (++ks == p.R) { ks = 0; ++kr; } }
+        if (kr < p.R && c0 == Cin) { c0 = 0; if (++ks == p.R) { ks = 0; ++kr; } }
     };
     auto stage = [&](int buf, int kt) {
         stage_begin(buf, kt);
@@ -330,6 +354,13 @@ conv_igemm_kernel(const ConvKP p) {
     float bias[VEC], ssum[VEC], ssq[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { bias[e] = (p.bias && n_ok) ? p.bias[n + e] : 0.f; ssum[e] = 0.f; ssq[e] = 0.f; }
+    // when a wave's WM rows lie inside one image its temb row is one vector: fold it into the bias
+    const bool temb_rowwise = p.temb && (HoWo % WM != 0);
+    if (p.temb && !temb_rowwise && n_ok && m0 + wr * WM < p.M) {
+        const float* tp = p.temb + (size_t)p.dHoWo.div((unsigned)(m0 + wr * WM)) * p.temb_stride + n;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) bias[e] += tp[e];
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -354,7 +385,7 @@ conv_igemm_kernel(const ConvKP p) {
                 const size_t o = (size_t)m * p.Cout + n;
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) v[e] += bias[e];
-                if (p.temb) {
+                if (temb_rowwise) {
                     const float* tp = p.temb + (size_t)p.dHoWo.div((unsigned)m) * p.temb_stride + n;
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) v[e] += tp[e];
@@ -459,10 +490,13 @@ extern "C" int advs_conv2d(const advs_conv_args* a, void* stream) {
     ADVS_REQUIRE(a->stride == 1 || a->stride == 2, "conv2d: stride %d unsupported", a->stride);
     ADVS_REQUIRE(a->pad >= 0 && a->pad <= 1, "conv2d: pad %d unsupported", a->pad);
     ADVS_REQUIRE((a->c2 == 0) == (a->x2 == nullptr), "conv2d: x2/c2 mismatch");
+    ADVS_REQUIRE((a->ce1 == 0) == (a->e1 == nullptr) && (a->ce2 == 0) == (a->e2 == nullptr) && (a->e1 || !a->e2),
+                 "conv2d: extra operand pointers/channels mismatch");
+    ADVS_REQUIRE(!a->e1 || a->stride == 1, "conv2d: the extra 1x1 operand needs stride 1");
     const int esz = a->dtype == ADVS_BF16 ? 2 : 4;
     const int bke = SLAB / esz;
-    ADVS_REQUIRE(a->c1 % bke == 0 && a->c2 % bke == 0, "conv2d: channels (%d,%d) must be multiples of %d",
-                 a->c1, a->c2, bke);
+    ADVS_REQUIRE(a->c1 % bke == 0 && a->c2 % bke == 0 && a->ce1 % bke == 0 && a->ce2 % bke == 0,
+                 "conv2d: channels (%d,%d | %d,%d) must be multiples of %d", a->c1, a->c2, a->ce1, a->ce2, bke);
     ADVS_REQUIRE(a->cout % (16 / esz) == 0, "conv2d: cout=%d must be a multiple of %d", a->cout, 16 / esz);
     ConvKP p;
     p.x1 = (const char*)a->x1; p.x2 = (const char*)a->x2; p.w = (const char*)a->w;
@@ -476,7 +510,11 @@ extern "C" int advs_conv2d(const advs_conv_args* a, void* stream) {
     const long long M = (long long)a->b * p.Ho * p.Wo;
     ADVS_REQUIRE(M > 0 && M < (1ll << 31) - 256, "conv2d: M=%lld out of range", M);
     p.M = (int)M;
-    p.K = a->ksize * a->ksize * (a->c1 + a->c2);
+    p.K = a->ksize * a->ksize * (a->c1 + a->c2) + a->ce1 + a->ce2;
+    p.e1 = (const char*)a->e1; p.e2 = (const char*)a->e2; p.E1 = a->ce1; p.E2 = a->ce2;
+    const unsigned long long e1b = (unsigned long long)M * a->ce1 * esz, e2b = (unsigned long long)M * a->ce2 * esz;
+    ADVS_REQUIRE(e1b < 0xF0000000ull && e2b < 0xF0000000ull, "conv2d: extra operand exceeds the 32-bit buffer offsets");
+    p.e1_bytes = (unsigned)(a->e1 ? e1b : 16); p.e2_bytes = (unsigned)(a->e2 ? e2b : 16);
     const unsigned long long x1b = (unsigned long long)a->b * a->h * a->w_ * a->c1 * esz;
     const unsigned long long x2b = (unsigned long long)a->b * a->h * a->w_ * a->c2 * esz;
     const unsigned long long wb = (unsigned long long)a->cout * p.K * esz;

@@ -175,8 +175,10 @@ class UNetModel(nn.Module):
                         W[p + n + ".w"] = pack_conv_weight(sd[p + n + ".weight"], dt)
                         W[p + n + ".b"] = sd[p + n + ".bias"].float().contiguous()
                     if cin != cout:
-                        W[p + ".shortcut.w"] = pack_conv_weight(sd[p + ".shortcut.weight"], dt)
-                        W[p + ".shortcut.b"] = sd[p + ".shortcut.bias"].float().contiguous()
+                        # shortcut fused into conv2: K = [9*cout | cin], one bias (diff_model.py:102-103)
+                        ws = pack_conv_weight(sd[p + ".shortcut.weight"], dt)
+                        W[p + ".conv2.3.w"] = torch.cat([W[p + ".conv2.3.w"].reshape(cout, -1), ws.reshape(cout, -1)], 1).contiguous()
+                        W[p + ".conv2.3.b"] = (W[p + ".conv2.3.b"] + sd[p + ".shortcut.bias"].float()).contiguous()
                     temb_w.append(sd[p + ".time_emb.1.weight"].float())
                     temb_b.append(sd[p + ".time_emb.1.bias"].float())
                     W["temb_off"][p] = off
@@ -286,15 +288,12 @@ def emit_unet_forward(bld, model, W, x_nchw, t_dev, eps_out):
         bld.free(a1)
         a2 = bld.groupnorm(h1, W[p + ".conv2.0.g"], W[p + ".conv2.0.b"], 32, act="silu")
         bld.free(h1)
-        if cin != cout:
-            sc = bld.conv(x1, W[p + ".shortcut.w"], cout, x2=x2, bias=W[p + ".shortcut.b"], ksize=1, pad=0)
+        if cin != cout:     # conv2(h) + shortcut(cat[x1, x2]) as one implicit GEMM over K = [9*cout | cin]
+            y = bld.conv(a2, W[p + ".conv2.3.w"], cout, bias=W[p + ".conv2.3.b"], extra=(x1, x2), want_stats=True)
         else:
             assert x2 is None
-            sc = x1
-        y = bld.conv(a2, W[p + ".conv2.3.w"], cout, bias=W[p + ".conv2.3.b"], residual=sc, want_stats=True)
+            y = bld.conv(a2, W[p + ".conv2.3.w"], cout, bias=W[p + ".conv2.3.b"], residual=x1, want_stats=True)
         bld.free(a2)
-        if sc is not x1:
-            bld.free(sc)
         return y
 
     def attn_block(p, ch, x):

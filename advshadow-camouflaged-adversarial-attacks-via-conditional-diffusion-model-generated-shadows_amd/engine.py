@@ -139,7 +139,9 @@ class Builder:
 
     # ---- ops (activations are NHWC tensors [B,H,W,C] of the compute dtype)
     def conv(self, x1, w, cout, *, x2=None, bias=None, temb=None, temb_stride=0, residual=None,
-             ksize=3, stride=1, pad=1, upsample=False, act=None, out=None, tile=0, want_stats=False):
+             ksize=3, stride=1, pad=1, upsample=False, act=None, out=None, tile=0, want_stats=False, extra=None):
+        """extra = (e1, e2_or_None): NHWC tensors at the OUTPUT resolution whose 1x1 conv is summed in;
+        ``w`` then holds [taps * (C1 + C2) | E1 + E2] per output channel."""
         B, H, W, C1 = x1.shape
         C2 = 0 if x2 is None else x2.shape[3]
         HL, WL = (H * 2, W * 2) if upsample else (H, W)
@@ -156,8 +158,10 @@ class Builder:
                 self.stats[y.data_ptr()] = (stats, Ho * Wo // rows)
         a = ConvArgs(ptr(x1), ptr(x2), ptr(w), ptr(bias), ptr(temb), ptr(residual), ptr(y),
                      B, H, W, C1, C2, cout, ksize, stride, pad, 1 if upsample else 0,
-                     ACT[act], self.dt, temb_stride, tile, ptr(stats), rows if stats is not None else 0)
-        self.plan.add(self.lib.advs_conv2d, C.byref(a), keep=(a, x1, x2, w, bias, temb, residual, y, stats))
+                     ACT[act], self.dt, temb_stride, tile, ptr(stats), rows if stats is not None else 0,
+                     ptr(extra[0]) if extra else 0, ptr(extra[1]) if extra and extra[1] is not None else 0,
+                     extra[0].shape[3] if extra else 0, extra[1].shape[3] if extra and extra[1] is not None else 0)
+        self.plan.add(self.lib.advs_conv2d, C.byref(a), keep=(a, x1, x2, w, bias, temb, residual, y, stats, extra))
         return y
 
     def conv_first(self, x_nchw, w, bias, cout):

@@ -67,6 +67,10 @@ typedef struct advs_conv_args {
                                            advs_conv_tile_rows(tile), must divide ho*wo) and channel the
                                            (sum, sum of squares) of y as stored -> advs_groupnorm_stats */
     int stats_rows;                     /* the row-block height `stats` was sized for (checked)          */
+    const void* e1; const void* e2;     /* extra 1x1 stride-1 operand [b][ho][wo][ce1],[...][ce2] or NULL:
+                                           y = conv(x) + conv1x1(cat(e1,e2)); w rows are then
+                                           [ksize*ksize*(c1+c2) | ce1+ce2] (h + shortcut(x), diff_model.py:103) */
+    int ce1, ce2;
 } advs_conv_args;
 int advs_conv2d(const advs_conv_args* a, void* stream);
 int advs_conv_set_tile(int tile);       /* tuning hook: non-zero overrides every call's tile  */

@@ -373,3 +373,27 @@ def test_groupnorm_with_epilogue_stats(dt, tiles):
     op.go()
     err = (nchw(y) - ref).abs().max().item()
     assert err < tol(dt, 3e-5, 4e-2), err
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("tile", [0, 1, 4])
+@pytest.mark.parametrize("two", [False, True])
+def test_conv2d_with_extra_1x1_operand(dt, tile, two):
+    """y = conv3x3(a) + conv1x1(cat[e1, e2]) + bias in one launch (residual block with a shortcut conv)."""
+    B, H, W, Ca, Cout, E1, E2 = 2, 12, 12, 128, 128, 64, (128 if two else 0)
+    a, e1 = rnd(B, Ca, H, W, seed=51), rnd(B, E1, H, W, seed=52)
+    e2 = rnd(B, E2, H, W, seed=53) if two else None
+    w3 = rnd(Cout, Ca, 3, 3, seed=54, scale=1 / math.sqrt(9 * Ca))
+    w1 = rnd(Cout, E1 + E2, 1, 1, seed=55, scale=1 / math.sqrt(E1 + E2))
+    bias = rnd(Cout, seed=56)
+    r = (lambda t: bf16_round(t)) if dt == "bf16" else (lambda t: t)
+    e = e1 if e2 is None else torch.cat([e1, e2], 1)
+    ref = F.conv2d(r(a), r(w3), bias, padding=1) + F.conv2d(r(e), r(w1))
+    code = dtype_code(dt)
+    wcat = torch.cat([pack_conv_weight(w3.to(dev()), code).reshape(Cout, -1),
+                      pack_conv_weight(w1.to(dev()), code).reshape(Cout, -1)], 1).contiguous()
+    op = OneOp(dt, B)
+    y = op.b.conv(nhwc(a, dt), wcat, Cout, bias=bias.to(dev()), extra=(nhwc(e1, dt), nhwc(e2, dt) if two else None), tile=tile)
+    op.go()
+    err = (nchw(y) - ref).abs().max().item()
+    assert err < tol(dt, 3e-5, 5e-2), err
