@@ -40,7 +40,11 @@ SIGNATURES = {
     "advs_groupnorm": [vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "advs_maxpool2": [vp, vp, i32, i32, i32, i32, i32, vp],
     "advs_concat_upsample2x": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
-    "advs_layernorm": [vp, vp, vp, vp, C.c_longlong, i32, i32, vp],
+    "advs_layernorm": [vp, vp, vp, vp, C.c_longlong, i32, f32, i32, vp],
+    "advs_attention_masked": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "advs_patchify": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "advs_vit_assemble": [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "advs_gather_rows_f32": [vp, vp, i32, C.c_longlong, i32, i32, vp],
     "advs_attention": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "advs_linear_f32": [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "advs_timestep_embedding": [vp, vp, i32, i32, vp, vp, vp, i32, vp],

@@ -17,6 +17,7 @@
 struct AttnP {
     const char* qkv; char* out;
     int B, N, heads, d, ld, q_off, k_off, v_off, head_stride;
+    int n_valid;                 // keys >= n_valid are padding: masked out of the softmax
     float scale_log2e;
 };
 
@@ -68,7 +69,7 @@ attn_kernel(const AttnP p) {
     const int cpr = d * ESZ / 16;                 // 16-byte chunks per K/V row
     const int nvec = KT * cpr;
 
-    for (int k0 = 0; k0 < p.N; k0 += KT) {
+    for (int k0 = 0; k0 < p.n_valid; k0 += KT) {
         __syncthreads();                          // previous tile fully consumed
         for (int v = tid; v < nvec; v += AT_THREADS) {
             const int key = v / cpr, ch = v - key * cpr;
@@ -117,7 +118,11 @@ attn_kernel(const AttnP p) {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { st[kb][r] *= p.scale_log2e; mx = fmaxf(mx, st[kb][r]); }
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                st[kb][r] = key < p.n_valid ? st[kb][r] * p.scale_log2e : -INFINITY;
+                mx = fmaxf(mx, st[kb][r]);
+            }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float m_new = fmaxf(m_run, mx);
         const float alpha = exp2f(m_run - m_new);          // exp2(-inf) = 0 on the first tile
@@ -206,10 +211,11 @@ static int attn_launch(const AttnP& p, hipStream_t st) {
     }
 }
 
-extern "C" int advs_attention(const void* qkv, void* out, int b, int n, int heads, int d, int ld,
-                              int q_off, int k_off, int v_off, int head_stride, int dtype, void* stream) {
+static int attention_impl(const void* qkv, void* out, int b, int n, int n_valid, int heads, int d, int ld,
+                          int q_off, int k_off, int v_off, int head_stride, int dtype, void* stream) {
     ADVS_REQUIRE(qkv && out && b > 0 && n > 0 && heads > 0 && d > 0, "attention: bad args");
     ADVS_REQUIRE(n % KT == 0, "attention: n=%d must be a multiple of %d", n, KT);
+    ADVS_REQUIRE(n_valid > 0 && n_valid <= n, "attention: n_valid=%d out of range", n_valid);
     ADVS_REQUIRE(d % 16 == 0 && d <= 128, "attention: d=%d must be a multiple of 16 and <= 128", d);
     const int vec = dtype == ADVS_BF16 ? 8 : 4;
     ADVS_REQUIRE(ld % vec == 0 && q_off % vec == 0 && k_off % vec == 0 && v_off % vec == 0 && head_stride % vec == 0,
@@ -217,8 +223,19 @@ extern "C" int advs_attention(const void* qkv, void* out, int b, int n, int head
     AttnP p;
     p.qkv = (const char*)qkv; p.out = (char*)out;
     p.B = b; p.N = n; p.heads = heads; p.d = d; p.ld = ld;
-    p.q_off = q_off; p.k_off = k_off; p.v_off = v_off; p.head_stride = head_stride;
+    p.q_off = q_off; p.k_off = k_off; p.v_off = v_off; p.head_stride = head_stride; p.n_valid = n_valid;
     p.scale_log2e = (float)(1.4426950408889634 / sqrt((double)d));
     if (dtype == ADVS_BF16) return attn_launch<BF16>(p, (hipStream_t)stream);
     return attn_launch<float>(p, (hipStream_t)stream);
+}
+
+extern "C" int advs_attention(const void* qkv, void* out, int b, int n, int heads, int d, int ld,
+                              int q_off, int k_off, int v_off, int head_stride, int dtype, void* stream) {
+    return attention_impl(qkv, out, b, n, n, heads, d, ld, q_off, k_off, v_off, head_stride, dtype, stream);
+}
+// Same with the token axis padded to a multiple of 64: only the first n_valid tokens are real keys
+// (ViT: 197 tokens in rows of 256); padded query rows produce values nobody reads.
+extern "C" int advs_attention_masked(const void* qkv, void* out, int b, int n, int n_valid, int heads, int d, int ld,
+                                     int q_off, int k_off, int v_off, int head_stride, int dtype, void* stream) {
+    return attention_impl(qkv, out, b, n, n_valid, heads, d, ld, q_off, k_off, v_off, head_stride, dtype, stream);
 }

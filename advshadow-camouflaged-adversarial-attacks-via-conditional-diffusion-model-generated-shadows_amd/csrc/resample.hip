@@ -104,7 +104,7 @@ extern "C" int advs_concat_upsample2x(const void* skip, const void* x, void* y, 
 template <typename T>
 __global__ void __launch_bounds__(256)
 layernorm_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
-                 T* __restrict__ y, long long rows, int C) {
+                 T* __restrict__ y, long long rows, int C, float eps) {
     constexpr int VEC = Elt<T>::VEC;
     const int l16 = threadIdx.x & 15;
     const int vpr = C / VEC;
@@ -132,7 +132,7 @@ layernorm_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const
         }
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o);
-        const float rstd = 1.0f / sqrtf(q / (float)C + 1e-5f);
+        const float rstd = 1.0f / sqrtf(q / (float)C + eps);
         if (!live) continue;
         u32x4* yr = (u32x4*)(y + (size_t)row * C);
         for (int cv = l16; cv < vpr; cv += 16) {
@@ -149,16 +149,16 @@ layernorm_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const
 }
 
 extern "C" int advs_layernorm(const void* x, const float* gamma, const float* beta, void* y, long long rows, int c,
-                              int dtype, void* stream) {
+                              float eps, int dtype, void* stream) {
     ADVS_REQUIRE(x && gamma && beta && y && rows > 0 && c > 0, "layernorm: bad args");
     const int vec = dtype == ADVS_BF16 ? 8 : 4;
     ADVS_REQUIRE(c % vec == 0, "layernorm: c=%d must be a multiple of %d", c, vec);
     long long blocks = (rows + 15) / 16;
     const int grid = (int)(blocks < 8192 ? blocks : 8192);
     if (dtype == ADVS_BF16)
-        layernorm_kernel<BF16><<<grid, 256, 0, (hipStream_t)stream>>>((const BF16*)x, gamma, beta, (BF16*)y, rows, c);
+        layernorm_kernel<BF16><<<grid, 256, 0, (hipStream_t)stream>>>((const BF16*)x, gamma, beta, (BF16*)y, rows, c, eps);
     else
-        layernorm_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>((const float*)x, gamma, beta, (float*)y, rows, c);
+        layernorm_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>((const float*)x, gamma, beta, (float*)y, rows, c, eps);
     ADVS_CHECK_LAUNCH("layernorm");
     return ADVS_OK;
 }

@@ -144,3 +144,75 @@ extern "C" int advs_global_avgpool(const void* x, float* y, int b, int hw, int c
     ADVS_CHECK_LAUNCH("global_avgpool");
     return ADVS_OK;
 }
+
+// ================================================================ ViT token plumbing (HF ViTForImageClassification)
+// patchify: NCHW f32 image -> [B][gh][gw][cin*ps*ps] T, channel = c*ps*ps + ky*ps + kx, i.e. the K order of the
+// patch-embedding Conv2d(cin, hidden, ps, stride ps) weight viewed as [hidden][cin*ps*ps]; the projection itself
+// is then an advs_conv2d 1x1.
+template <typename T>
+__global__ void patchify_kernel(const float* __restrict__ x, T* __restrict__ y, int B, int Cin, int H, int W, int ps) {
+    const int gh = H / ps, gw = W / ps, K = Cin * ps * ps;
+    const size_t total = (size_t)B * gh * gw * K;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % K);
+        size_t r = i / K;
+        const int px = (int)(r % gw); r /= gw;
+        const int py = (int)(r % gh);
+        const int b = (int)(r / gh);
+        const int c = k / (ps * ps), ky = (k / ps) % ps, kx = k % ps;
+        Elt<T>::st(y + i, x[(((size_t)b * Cin + c) * H + py * ps + ky) * W + px * ps + kx]);
+    }
+}
+extern "C" int advs_patchify(const float* x_nchw, void* y, int b, int cin, int h, int w, int patch, int dtype, void* stream) {
+    ADVS_REQUIRE(x_nchw && y && b > 0 && cin > 0 && patch > 0 && h % patch == 0 && w % patch == 0, "patchify: bad args");
+    const size_t total = (size_t)b * cin * h * w;
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (dtype == ADVS_BF16) patchify_kernel<BF16><<<grid, 256, 0, (hipStream_t)stream>>>(x_nchw, (BF16*)y, b, cin, h, w, patch);
+    else patchify_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>(x_nchw, (float*)y, b, cin, h, w, patch);
+    ADVS_CHECK_LAUNCH("patchify");
+    return ADVS_OK;
+}
+
+// tokens[b][0] = cls + pos[0]; tokens[b][1+i] = patches[b][i] + pos[1+i]; rows >= 1+np are zero padding
+// (ViTEmbeddings.forward).  tokens is [B][n_pad][C] T, patches [B][np][C] T, cls [C] / pos [1+np][C] f32.
+template <typename T>
+__global__ void vit_assemble_kernel(const T* __restrict__ patches, const float* __restrict__ cls, const float* __restrict__ pos,
+                                    T* __restrict__ tokens, int B, int np, int n_pad, int C) {
+    const size_t total = (size_t)B * n_pad * C;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        size_t r = i / C;
+        const int t = (int)(r % n_pad);
+        const int b = (int)(r / n_pad);
+        float v = 0.f;
+        if (t == 0) v = cls[c] + pos[c];
+        else if (t <= np) v = Elt<T>::ld(patches + ((size_t)b * np + (t - 1)) * C + c) + pos[(size_t)t * C + c];
+        Elt<T>::st(tokens + i, v);
+    }
+}
+extern "C" int advs_vit_assemble(const void* patches, const float* cls, const float* pos, void* tokens, int b, int np,
+                                 int n_pad, int c, int dtype, void* stream) {
+    ADVS_REQUIRE(patches && cls && pos && tokens && b > 0 && np > 0 && n_pad > np && c > 0, "vit_assemble: bad args");
+    const size_t total = (size_t)b * n_pad * c;
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (dtype == ADVS_BF16) vit_assemble_kernel<BF16><<<grid, 256, 0, (hipStream_t)stream>>>((const BF16*)patches, cls, pos, (BF16*)tokens, b, np, n_pad, c);
+    else vit_assemble_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>((const float*)patches, cls, pos, (float*)tokens, b, np, n_pad, c);
+    ADVS_CHECK_LAUNCH("vit_assemble");
+    return ADVS_OK;
+}
+
+// rows [b*row_stride] of a [.][C] T matrix -> f32 [B][C] (the CLS token fed to the classifier head)
+template <typename T>
+__global__ void gather_rows_kernel(const T* __restrict__ x, float* __restrict__ y, int B, long long row_stride, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, c = i - b * C;
+    y[i] = Elt<T>::ld(x + (size_t)b * row_stride * C + c);
+}
+extern "C" int advs_gather_rows_f32(const void* x, float* y, int b, long long row_stride, int c, int dtype, void* stream) {
+    ADVS_REQUIRE(x && y && b > 0 && c > 0 && row_stride > 0, "gather_rows_f32: bad args");
+    if (dtype == ADVS_BF16) gather_rows_kernel<BF16><<<cdiv((long long)b * c, 256), 256, 0, (hipStream_t)stream>>>((const BF16*)x, y, b, row_stride, c);
+    else gather_rows_kernel<float><<<cdiv((long long)b * c, 256), 256, 0, (hipStream_t)stream>>>((const float*)x, y, b, row_stride, c);
+    ADVS_CHECK_LAUNCH("gather_rows_f32");
+    return ADVS_OK;
+}

@@ -208,18 +208,18 @@ class Builder:
                       keep=(skip, x, y))
         return y
 
-    def layernorm(self, x, gamma, beta):
+    def layernorm(self, x, gamma, beta, eps=1e-5):
         rows = x.numel() // x.shape[-1]
         y = self.buf(tuple(x.shape))
-        self.plan.add(self.lib.advs_layernorm, ptr(x), ptr(gamma), ptr(beta), ptr(y), rows, x.shape[-1], self.dt,
-                      keep=(x, gamma, beta, y))
+        self.plan.add(self.lib.advs_layernorm, ptr(x), ptr(gamma), ptr(beta), ptr(y), rows, x.shape[-1], float(eps),
+                      self.dt, keep=(x, gamma, beta, y))
         return y
 
-    def attention(self, qkv, heads, d, q_off, k_off, v_off, head_stride):
+    def attention(self, qkv, heads, d, q_off, k_off, v_off, head_stride, n_valid=None):
         B, H, W, LD = qkv.shape
         y = self.buf((B, H, W, heads * d))
-        self.plan.add(self.lib.advs_attention, ptr(qkv), ptr(y), B, H * W, heads, d, LD, q_off, k_off, v_off,
-                      head_stride, self.dt, keep=(qkv, y))
+        self.plan.add(self.lib.advs_attention_masked, ptr(qkv), ptr(y), B, H * W, n_valid or H * W, heads, d, LD,
+                      q_off, k_off, v_off, head_stride, self.dt, keep=(qkv, y))
         return y
 
     def linear(self, x, w, bias, act_in=None, act_out=None):

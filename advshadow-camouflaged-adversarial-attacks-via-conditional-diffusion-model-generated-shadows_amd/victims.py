@@ -150,3 +150,285 @@ class _ResNetEngine:
             self.plan.capture()
             self.captured = True
         self.plan.run()
+
+
+# ============================================================================ ViT (HF ViTForImageClassification)
+class _Logits:
+    """What the reference reads from a HF model: ``outputs.logits`` (ASR_fast.py:114)."""
+
+    def __init__(self, logits):
+        self.logits = logits
+
+
+# transformers >= 5 renamed the encoder parameters; the authors' checkpoints (4.x) use the left-hand names
+_VIT_NEW2OLD = (("vit.layers.", "vit.encoder.layer."), (".attention.q_proj.", ".attention.attention.query."),
+                (".attention.k_proj.", ".attention.attention.key."), (".attention.v_proj.", ".attention.attention.value."),
+                (".attention.o_proj.", ".attention.output.dense."), (".mlp.fc1.", ".intermediate.dense."),
+                (".mlp.fc2.", ".output.dense."))
+
+
+def vit_canonical_state_dict(sd):
+    """Map a transformers-5 style ViT state_dict onto the 4.x key names this module holds."""
+    out = {}
+    for k, v in sd.items():
+        for new, old in _VIT_NEW2OLD:
+            k = k.replace(new, old)
+        out[k] = v
+    return out
+
+
+class ViTVictim(nn.Module):
+    """ViT-B/16-style classifier with HF's parameter names (``AutoModelForImageClassification`` of
+    ASR_fast.py:47-51; config C4 of BASELINE.json), forward on the HIP kernels: patch projection and every
+    Linear as implicit-GEMM 1x1 convs (bias / GELU / residual in the epilogue), LayerNorm, flash attention
+    with the 197 tokens padded to 256 rows and the padding masked."""
+
+    def __init__(self, num_labels=37, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
+                 intermediate_size=3072, patch_size=16, image_size=224, layer_norm_eps=1e-12,
+                 compute_dtype="fp32", use_graph=True):
+        super().__init__()
+        self.cfg = dict(num_labels=num_labels, hidden=hidden_size, layers=num_hidden_layers, heads=num_attention_heads,
+                        mlp=intermediate_size, patch=patch_size, image=image_size, eps=layer_norm_eps)
+        self.compute_dtype, self.use_graph = compute_dtype, use_graph
+        C, npatch = hidden_size, (image_size // patch_size) ** 2
+
+        class _P(nn.Module):
+            def __init__(self, *shape):
+                super().__init__()
+
+        emb = nn.Module()
+        emb.cls_token = nn.Parameter(torch.randn(1, 1, C) * 0.02)
+        emb.position_embeddings = nn.Parameter(torch.randn(1, npatch + 1, C) * 0.02)
+        _attach(self, "vit.embeddings", emb)
+        _attach(self, "vit.embeddings.patch_embeddings.projection", nn.Conv2d(3, C, patch_size, stride=patch_size))
+        for i in range(num_hidden_layers):
+            p = f"vit.encoder.layer.{i}"
+            for n in ("query", "key", "value"):
+                _attach(self, f"{p}.attention.attention.{n}", nn.Linear(C, C))
+            _attach(self, p + ".attention.output.dense", nn.Linear(C, C))
+            _attach(self, p + ".intermediate.dense", nn.Linear(C, intermediate_size))
+            _attach(self, p + ".output.dense", nn.Linear(intermediate_size, C))
+            _attach(self, p + ".layernorm_before", nn.LayerNorm(C, eps=layer_norm_eps))
+            _attach(self, p + ".layernorm_after", nn.LayerNorm(C, eps=layer_norm_eps))
+        _attach(self, "vit.layernorm", nn.LayerNorm(C, eps=layer_norm_eps))
+        _attach(self, "classifier", nn.Linear(C, num_labels))
+        self._packed, self._engines = {}, {}
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        return super().load_state_dict(vit_canonical_state_dict(state_dict), strict=strict, **kw)
+
+    def _version(self):
+        return (str(next(self.parameters()).device), sum(p._version for p in self.parameters()))
+
+    def packed_weights(self, dt):
+        ver = self._version()
+        hit = self._packed.get(dt)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise _lib.AdvsError(f"ViTVictim parameters are on {dev}: move the model to the GPU; there is no CPU fallback")
+        sd = {k: v.detach() for k, v in self.state_dict().items()}
+        f32 = lambda k: sd[k].float().contiguous()
+        lin = lambda k: pack_conv_weight(sd[k].float().reshape(sd[k].shape[0], -1, 1, 1), dt)
+        W = {"cls": f32("vit.embeddings.cls_token").reshape(-1), "pos": f32("vit.embeddings.position_embeddings")[0].contiguous(),
+             "proj.w": lin("vit.embeddings.patch_embeddings.projection.weight"),
+             "proj.b": f32("vit.embeddings.patch_embeddings.projection.bias")}
+        for i in range(self.cfg["layers"]):
+            p = f"vit.encoder.layer.{i}"
+            a = p + ".attention.attention."
+            W[p + ".qkv.w"] = pack_conv_weight(torch.cat([sd[a + n + ".weight"].float() for n in ("query", "key", "value")], 0)
+                                               .reshape(3 * self.cfg["hidden"], -1, 1, 1), dt)
+            W[p + ".qkv.b"] = torch.cat([sd[a + n + ".bias"].float() for n in ("query", "key", "value")], 0).contiguous()
+            for src, dst in ((".attention.output.dense", ".o"), (".intermediate.dense", ".fc1"), (".output.dense", ".fc2")):
+                W[p + dst + ".w"], W[p + dst + ".b"] = lin(p + src + ".weight"), f32(p + src + ".bias")
+            for n in (".layernorm_before", ".layernorm_after"):
+                W[p + n + ".g"], W[p + n + ".b"] = f32(p + n + ".weight"), f32(p + n + ".bias")
+        W["ln.g"], W["ln.b"] = f32("vit.layernorm.weight"), f32("vit.layernorm.bias")
+        W["cls.w"], W["cls.b"] = f32("classifier.weight"), f32("classifier.bias")
+        self._packed[dt] = (ver, W)
+        for key in [k for k in self._engines if k[1] == dt]:
+            del self._engines[key]
+        return W
+
+    def engine(self, batch, dtype=None):
+        dt = dtype_code(dtype if dtype is not None else self.compute_dtype)
+        W = self.packed_weights(dt)
+        eng = self._engines.get((batch, dt))
+        if eng is None:
+            eng = _ViTEngine(self, W, batch, dt)
+            self._engines[(batch, dt)] = eng
+        return eng
+
+    def forward(self, pixel_values):
+        B = pixel_values.shape[0]
+        eng = self.engine(B)
+        cur = torch.cuda.current_stream(pixel_values.device)
+        eng.stream.wait_stream(cur)
+        with torch.cuda.stream(eng.stream):
+            eng.x.copy_(pixel_values.to(torch.float32), non_blocking=True)
+            eng.run()
+            out = eng.logits.clone()
+        cur.wait_stream(eng.stream)
+        out.record_stream(cur)
+        return _Logits(out)
+
+
+class _ViTEngine:
+    def __init__(self, model, W, batch, dt):
+        cfg = model.cfg
+        dev = next(model.parameters()).device
+        self.model, self.stream = model, torch.cuda.Stream(device=dev)
+        C, heads, S, ps, eps = cfg["hidden"], cfg["heads"], cfg["image"], cfg["patch"], cfg["eps"]
+        g = S // ps
+        npatch, n_tok = g * g, g * g + 1
+        n_pad = (n_tok + 63) // 64 * 64
+        d = C // heads
+        with torch.cuda.device(dev):
+            bld = Builder(dev, dt, self.stream, batch)
+            lib = bld.lib
+            self.x = torch.zeros((batch, 3, S, S), dtype=torch.float32, device=dev)
+            patches = bld.buf((batch, g, g, 3 * ps * ps))
+            bld.plan.add(lib.advs_patchify, ptr(self.x), ptr(patches), batch, 3, S, S, ps, dt, keep=(self.x, patches))
+            emb = bld.conv(patches, W["proj.w"], C, bias=W["proj.b"], ksize=1, pad=0)
+            bld.free(patches)
+            tok = bld.buf((batch, 1, n_pad, C))
+            bld.plan.add(lib.advs_vit_assemble, ptr(emb), ptr(W["cls"]), ptr(W["pos"]), ptr(tok), batch, npatch, n_pad, C, dt,
+                         keep=(emb, tok))
+            bld.free(emb)
+            for i in range(cfg["layers"]):
+                p = f"vit.encoder.layer.{i}"
+                ln = bld.layernorm(tok, W[p + ".layernorm_before.g"], W[p + ".layernorm_before.b"], eps)
+                qkv = bld.conv(ln, W[p + ".qkv.w"], 3 * C, bias=W[p + ".qkv.b"], ksize=1, pad=0)
+                bld.free(ln)
+                att = bld.attention(qkv, heads, d, 0, C, 2 * C, d, n_valid=n_tok)
+                bld.free(qkv)
+                h = bld.conv(att, W[p + ".o.w"], C, bias=W[p + ".o.b"], residual=tok, ksize=1, pad=0)
+                bld.free(att)
+                bld.free(tok)
+                ln = bld.layernorm(h, W[p + ".layernorm_after.g"], W[p + ".layernorm_after.b"], eps)
+                f = bld.conv(ln, W[p + ".fc1.w"], cfg["mlp"], bias=W[p + ".fc1.b"], act="gelu", ksize=1, pad=0)
+                bld.free(ln)
+                tok = bld.conv(f, W[p + ".fc2.w"], C, bias=W[p + ".fc2.b"], residual=h, ksize=1, pad=0)
+                bld.free(f)
+                bld.free(h)
+            ln = bld.layernorm(tok, W["ln.g"], W["ln.b"], eps)
+            bld.free(tok)
+            cls = bld.buf((batch, C), torch.float32)
+            bld.plan.add(lib.advs_gather_rows_f32, ptr(ln), ptr(cls), batch, n_pad, C, dt, keep=(ln, cls))
+            self.logits = bld.linear(cls, W["cls.w"], W["cls.b"])
+            self.plan, self.captured = bld.plan, False
+            torch.cuda.synchronize(dev)
+
+    def run(self):
+        if self.model.use_graph and not self.captured:
+            self.plan.run_eager()
+            self.stream.synchronize()
+            self.plan.capture()
+            self.captured = True
+        self.plan.run()
+
+
+# ============================================================================ VGG-16 / VGG-19 (torchvision names)
+_VGG_CFG = {16: [64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M"],
+            19: [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M"]}
+
+
+class VGG(nn.Module):
+    """torchvision ``vgg16()`` / ``vgg19()`` with ``classifier[6] = Linear(4096, 37)`` (ASR_fast.py:33-46):
+    ``features.{i}`` convs (bias + ReLU in the conv epilogue), MaxPool2d(2), three Linear layers."""
+
+    def __init__(self, depth=16, num_classes=37, compute_dtype="fp32", use_graph=True):
+        super().__init__()
+        self.depth, self.num_classes, self.compute_dtype, self.use_graph = depth, num_classes, compute_dtype, use_graph
+        self.layers, cin, idx = [], 3, 0
+        for v in _VGG_CFG[depth]:
+            if v == "M":
+                self.layers.append(("pool", None, 0, 0))
+                idx += 1
+            else:
+                _attach(self, f"features.{idx}", nn.Conv2d(cin, v, 3, padding=1))
+                self.layers.append(("conv", f"features.{idx}", cin, v))
+                cin, idx = v, idx + 2                     # conv, ReLU
+        for i, (a, b) in zip((0, 3, 6), ((512 * 7 * 7, 4096), (4096, 4096), (4096, num_classes))):
+            _attach(self, f"classifier.{i}", nn.Linear(a, b))
+        self._packed, self._engines = {}, {}
+
+    def _version(self):
+        return (str(next(self.parameters()).device), sum(p._version for p in self.parameters()))
+
+    def packed_weights(self, dt):
+        ver = self._version()
+        hit = self._packed.get(dt)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise _lib.AdvsError(f"VGG parameters are on {dev}: move the model to the GPU; there is no CPU fallback")
+        sd = {k: v.detach() for k, v in self.state_dict().items()}
+        W = {}
+        for kind, p, cin, cout in self.layers:
+            if kind == "conv":
+                W[p + ".w"] = sd[p + ".weight"].float().contiguous() if cin == 3 else pack_conv_weight(sd[p + ".weight"], dt)
+                W[p + ".b"] = sd[p + ".bias"].float().contiguous()
+        for i in (0, 3, 6):
+            W[f"fc{i}.w"], W[f"fc{i}.b"] = sd[f"classifier.{i}.weight"].float().contiguous(), sd[f"classifier.{i}.bias"].float().contiguous()
+        self._packed[dt] = (ver, W)
+        for key in [k for k in self._engines if k[2] == dt]:
+            del self._engines[key]
+        return W
+
+    def engine(self, batch, size, dtype=None):
+        dt = dtype_code(dtype if dtype is not None else self.compute_dtype)
+        W = self.packed_weights(dt)
+        eng = self._engines.get((batch, size, dt))
+        if eng is None:
+            eng = _VGGEngine(self, W, batch, size, dt)
+            self._engines[(batch, size, dt)] = eng
+        return eng
+
+    def forward(self, x):
+        B, _, H, Wd = x.shape
+        if H != 224 or Wd != 224:
+            raise ValueError("VGG victim expects 224x224 inputs (AdaptiveAvgPool2d(7) is the identity there)")
+        eng = self.engine(B, H)
+        cur = torch.cuda.current_stream(x.device)
+        eng.stream.wait_stream(cur)
+        with torch.cuda.stream(eng.stream):
+            eng.x.copy_(x.to(torch.float32), non_blocking=True)
+            eng.run()
+            out = eng.logits.clone()
+        cur.wait_stream(eng.stream)
+        out.record_stream(cur)
+        return out
+
+
+class _VGGEngine(_ResNetEngine):
+    def __init__(self, model, W, batch, size, dt):
+        dev = next(model.parameters()).device
+        self.model, self.stream = model, torch.cuda.Stream(device=dev)
+        with torch.cuda.device(dev):
+            bld = Builder(dev, dt, self.stream, batch)
+            lib = bld.lib
+            self.x = torch.zeros((batch, 3, size, size), dtype=torch.float32, device=dev)
+            h, hw = None, size
+            for kind, p, cin, cout in model.layers:
+                if kind == "conv" and cin == 3:
+                    new = bld.buf((batch, hw, hw, cout))
+                    bld.plan.add(lib.advs_conv_stem, ptr(self.x), ptr(W[p + ".w"]), ptr(W[p + ".b"]), ptr(new), batch, 3, hw, hw,
+                                 cout, 3, 1, 1, _lib.ACT["relu"], dt, keep=(self.x, new))
+                elif kind == "conv":
+                    new = bld.conv(h, W[p + ".w"], cout, bias=W[p + ".b"], act="relu")
+                else:
+                    new = bld.maxpool2(h)
+                    hw //= 2
+                if h is not None:
+                    bld.free(h)
+                h = new
+            flat = bld.buf((batch, 512, hw, hw), torch.float32)           # x.view(B, -1) flattens NCHW
+            bld.plan.add(lib.advs_nhwc_to_nchw_f32, ptr(h), ptr(flat), batch, 512, hw, hw, dt, keep=(h, flat))
+            f = bld.linear(flat.view(batch, -1), W["fc0.w"], W["fc0.b"], act_out="relu")
+            f = bld.linear(f, W["fc3.w"], W["fc3.b"], act_out="relu")
+            self.logits = bld.linear(f, W["fc6.w"], W["fc6.b"])
+            self.plan, self.captured = bld.plan, False
+            torch.cuda.synchronize(dev)

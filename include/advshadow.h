@@ -117,9 +117,9 @@ int advs_maxpool2(const void* x, void* y, int b, int h, int w, int c, int dtype,
  * (block.py:66,86-87): skip [b][2h][2w][c1], x [b][h][w][c2] -> y [b][2h][2w][c1+c2].          */
 int advs_concat_upsample2x(const void* skip, const void* x, void* y, int b, int h, int w, int c1, int c2,
                            int dtype, void* stream);
-/* nn.LayerNorm([c]) over the last axis of [rows][c], eps 1e-5 (model/modules/attention.py:25,27). */
+/* nn.LayerNorm([c]) over the last axis of [rows][c] (model/modules/attention.py:25,27: eps 1e-5; HF ViT: 1e-12). */
 int advs_layernorm(const void* x, const float* gamma, const float* beta, void* y, long long rows, int c,
-                   int dtype, void* stream);
+                   float eps, int dtype, void* stream);
 
 /* ---- self-attention, flash style -------------------------------------------------------
  * softmax(q k^T / sqrt(d)) v per (batch, head) without materialising the N x N scores
@@ -129,6 +129,10 @@ int advs_layernorm(const void* x, const float* gamma, const float* beta, void* y
  * n multiple of 32, d multiple of 16, d <= 128.                                          */
 int advs_attention(const void* qkv, void* out, int b, int n, int heads, int d, int ld,
                    int q_off, int k_off, int v_off, int head_stride, int dtype, void* stream);
+
+/* Token axis padded to a multiple of 64 (ViT: 197 tokens in rows of 256): keys >= n_valid are masked.  */
+int advs_attention_masked(const void* qkv, void* out, int b, int n, int n_valid, int heads, int d, int ld,
+                          int q_off, int k_off, int v_off, int head_stride, int dtype, void* stream);
 
 /* ---- small dense layers of the time-embedding path (always f32) ------------------------
  * y[b][n] = bias[n] + sum_k act_in(x[b][k]) * w[n][k]   (nn.Linear after optional SiLU:
@@ -201,6 +205,14 @@ int advs_conv_stem(const float* x_nchw, const float* w_oihw, const float* bias, 
                    int dtype, void* stream);
 int advs_maxpool3x3s2(const void* x, void* y, int b, int h, int w, int c, int dtype, void* stream); /* MaxPool2d(3,2,1) */
 int advs_global_avgpool(const void* x, float* y, int b, int hw, int c, int dtype, void* stream);    /* -> f32 [b][c] */
+
+/* HF ViTForImageClassification victim (ASR_fast.py:47-51) token plumbing: image -> patch rows whose K order is
+ * the patch-embedding conv weight's ([hidden][cin*ps*ps]); tokens = [cls | patches] + position embeddings, rows
+ * padded with zeros to n_pad; CLS rows gathered to f32 for the classifier head.                                */
+int advs_patchify(const float* x_nchw, void* y, int b, int cin, int h, int w, int patch, int dtype, void* stream);
+int advs_vit_assemble(const void* patches, const float* cls, const float* pos, void* tokens, int b, int np,
+                      int n_pad, int c, int dtype, void* stream);
+int advs_gather_rows_f32(const void* x, float* y, int b, long long row_stride, int c, int dtype, void* stream);
 
 /* ---- stream capture (hipGraph) -------------------------------------------------------- */
 int advs_graph_begin(void* stream);

@@ -48,3 +48,33 @@ def randomize_bn(sd, seed):
             elif k.endswith("bias"):
                 sd[k] = torch.randn(sd[k].shape, generator=g) * 0.1
     return sd
+
+
+# ---------------------------------------------------------------------------- VGG / ViT
+VGG_CFG = {16: [64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M"],
+           19: [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M"]}
+
+
+@torch.no_grad()
+def vgg_forward(sd, x, depth=16):
+    """torchvision VGG (features / avgpool / classifier), eval mode.  PARITY UNPINNED (torchvision absent)."""
+    idx = 0
+    for v in VGG_CFG[depth]:
+        if v == "M":
+            x = F.max_pool2d(x, 2)
+            idx += 1
+        else:
+            x = F.relu(F.conv2d(x, sd[f"features.{idx}.weight"], sd[f"features.{idx}.bias"], padding=1))
+            idx += 2
+    x = F.adaptive_avg_pool2d(x, 7).flatten(1)
+    x = F.relu(F.linear(x, sd["classifier.0.weight"], sd["classifier.0.bias"]))
+    x = F.relu(F.linear(x, sd["classifier.3.weight"], sd["classifier.3.bias"]))
+    return F.linear(x, sd["classifier.6.weight"], sd["classifier.6.bias"])
+
+
+def hf_vit(num_labels=37, seed=2, **cfg):
+    """The installed transformers ViTForImageClassification, random init: the one victim whose REAL
+    implementation is importable here, used as its own oracle."""
+    from transformers import ViTConfig, ViTForImageClassification
+    torch.manual_seed(seed)
+    return ViTForImageClassification(ViTConfig(num_labels=num_labels, **cfg)).eval()

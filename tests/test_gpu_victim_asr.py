@@ -103,3 +103,52 @@ def test_label_maps_from_reference_style_config(tmp_path):
     p.write_text(json.dumps({"id2label": {"0": "Abyssinian", "1": "Bengal"}}))
     l2i, i2l = asr.load_label_maps(str(p))
     assert l2i == {"Abyssinian": 0, "Bengal": 1} and i2l == {0: "Abyssinian", 1: "Bengal"}
+
+
+def test_vit_victim_matches_hf_transformers():
+    """ViT-B/16 (config C4's victim) against the installed transformers implementation itself."""
+    from advshadow_amd.victims import ViTVictim
+    hf = ov.hf_vit(37, seed=2)
+    net = ViTVictim(37)
+    net.load_state_dict(hf.state_dict())                  # transformers-5 key names are remapped
+    net = net.to("cuda").eval()
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(3, 3, 224, 224, generator=g)
+    with torch.no_grad():
+        ref = hf(pixel_values=x).logits
+    for _ in range(2):
+        got = net(x.cuda()).logits.cpu()
+        assert (got - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item())
+        assert torch.equal(got.argmax(1), ref.argmax(1))
+    bf = ViTVictim(37, compute_dtype="bf16")
+    bf.load_state_dict(hf.state_dict())
+    got = bf.to("cuda").eval()(x.cuda()).logits.cpu()
+    assert (got - ref).abs().max().item() < 0.05 * max(1.0, ref.abs().max().item())
+
+
+def test_vit_small_config_and_masking():
+    """A small ViT (2 layers, 4 heads, 64 px, 8 px patches -> 65 tokens padded to 128) vs transformers."""
+    from advshadow_amd.victims import ViTVictim
+    cfg = dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=4, intermediate_size=256, patch_size=8, image_size=64)
+    hf = ov.hf_vit(5, seed=3, **cfg)
+    net = ViTVictim(5, **cfg)
+    net.load_state_dict(hf.state_dict())
+    net = net.to("cuda").eval()
+    x = torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(9))
+    with torch.no_grad():
+        ref = hf(pixel_values=x).logits
+    got = net(x.cuda()).logits.cpu()
+    assert (got - ref).abs().max().item() < 2e-5
+
+
+def test_vgg16_matches_oracle():
+    from advshadow_amd.victims import VGG
+    torch.manual_seed(6)
+    net = VGG(16, 37)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    net = net.to("cuda").eval()
+    x = torch.rand(2, 3, 224, 224, generator=torch.Generator().manual_seed(7))
+    ref = ov.vgg_forward(sd, x, 16)
+    got = net(x.cuda()).cpu()
+    assert (got - ref).abs().max().item() < 1e-3 * max(1.0, ref.abs().max().item())
+    assert torch.equal(got.argmax(1), ref.argmax(1))
