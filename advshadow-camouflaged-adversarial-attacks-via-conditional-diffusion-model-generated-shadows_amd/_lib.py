@@ -49,6 +49,8 @@ SIGNATURES = {
     "advs_linear_f32": [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "advs_timestep_embedding": [vp, vp, i32, i32, vp, vp, vp, i32, vp],
     "advs_ddim_step": [vp, vp, vp, f32, vp, vp, vp, i32, vp, vp, i32, sz, i32, vp],
+    "advs_ddpm_step": [vp, vp, vp, f32, vp, vp, vp, i32, vp, vp, i32, sz, vp],
+    "advs_plms_combine": [vp, vp, f32, vp, vp, vp, vp, i32, vp, vp, sz, vp],
     "advs_to_uint8": [vp, vp, sz, i32, vp],
     "advs_unit_to_uint8": [vp, vp, sz, vp],
     "advs_apply_shadow": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, C.POINTER(f32), i32, vp],

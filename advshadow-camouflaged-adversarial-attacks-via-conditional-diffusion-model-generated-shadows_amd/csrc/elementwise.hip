@@ -241,3 +241,86 @@ extern "C" int advs_unit_to_uint8(const float* x, uint8_t* y, size_t n, void* st
     ADVS_CHECK_LAUNCH("unit_to_uint8");
     return ADVS_OK;
 }
+
+// ------------------------------------------------------------------ DDPM ancestral update (model/samples/ddpm.py:86-88)
+//   eps' = lerp(eps_u, eps, cfg) (optional);  x = 1/sqrt(alpha) * (x - ((1-alpha)/sqrt(1-alpha_hat)) * eps') + sqrt(beta)*noise
+// coef[step] = {alpha, alpha_hat, beta}.  Same device-side step counter / timestep hand-off as advs_ddim_step.
+__global__ void ddpm_step_kernel(float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ eps_u,
+                                 float cfg, const float* __restrict__ noise, const float* __restrict__ coef,
+                                 const int32_t* __restrict__ step_counter, size_t n4) {
+    const int step = *step_counter;
+    const float alpha = coef[3 * step], ahat = coef[3 * step + 1], beta = coef[3 * step + 2];
+    const float inv = 1.0f / sqrtf(alpha);
+    const float ce = (1.0f - alpha) / sqrtf(1.0f - ahat);
+    const float sb = sqrtf(beta);
+    const bool small = fabsf(cfg) < 0.5f;
+    const float coeff = small ? cfg : cfg - 1.0f;
+    const f32x4* e4 = (const f32x4*)eps;
+    const f32x4* u4 = (const f32x4*)eps_u;
+    const f32x4* z4 = (const f32x4*)noise;
+    f32x4* x4 = (f32x4*)x;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        f32x4 xv = x4[i], ev = e4[i], r, uv, zv;
+        if (eps_u) uv = u4[i];
+        if (noise) zv = z4[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float e = ev[j];
+            if (eps_u) { const float d = e - uv[j]; e = fmaf(coeff, d, small ? uv[j] : e); }
+            const float v = inv * (xv[j] - ce * e);
+            r[j] = v + sb * (noise ? zv[j] : 0.0f);
+        }
+        x4[i] = r;
+    }
+}
+
+extern "C" int advs_ddpm_step(float* x, const float* eps, const float* eps_uncond, float cfg_scale, const float* noise,
+                              const float* coef, const int64_t* tseq, int nsteps, int32_t* step_counter,
+                              int64_t* t_out, int b, size_t per_sample, void* stream) {
+    ADVS_REQUIRE(x && eps && coef && tseq && step_counter && t_out && b > 0 && nsteps > 0, "ddpm_step: bad args");
+    const size_t n = (size_t)b * per_sample;
+    ADVS_REQUIRE(n % 4 == 0, "ddpm_step: element count %zu not a multiple of 4", n);
+    const size_t n4 = n / 4;
+    const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    ddpm_step_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, eps, eps_uncond, cfg_scale, noise, coef, step_counter, n4);
+    ADVS_CHECK_LAUNCH("ddpm_step");
+    ddim_advance_kernel<<<1, 256, 0, (hipStream_t)stream>>>(step_counter, tseq, nsteps, t_out, b);
+    ADVS_CHECK_LAUNCH("ddpm_advance");
+    return ADVS_OK;
+}
+
+// ------------------------------------------------------------------ PLMS multistep combine (model/samples/plms.py:93-107)
+// out = lerp(eps_u, eps, cfg) first (optional), then by the number of stored predictions `order`:
+//   0 with `next`: (e + next)/2 ; 1: (3e - o1)/2 ; 2: (23e - 16 o1 + 5 o2)/12 ; 3+: (55e - 59 o1 + 37 o2 - 9 o3)/24
+// `guided` receives the lerped eps (what the reference appends to old_eps), `out` the combined one.
+__global__ void plms_combine_kernel(const float* __restrict__ eps, const float* __restrict__ eps_u, float cfg,
+                                    const float* __restrict__ nxt, const float* __restrict__ o1, const float* __restrict__ o2,
+                                    const float* __restrict__ o3, int order, float* __restrict__ guided,
+                                    float* __restrict__ out, size_t n) {
+    const bool small = fabsf(cfg) < 0.5f;
+    const float coeff = small ? cfg : cfg - 1.0f;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float e = eps[i];
+        if (eps_u) { const float u = eps_u[i], d = e - u; e = fmaf(coeff, d, small ? u : e); }
+        if (guided) guided[i] = e;
+        float r;
+        if (order == 0) r = nxt ? (e + nxt[i]) / 2.0f : e;
+        else if (order == 1) r = (3.0f * e - o1[i]) / 2.0f;
+        else if (order == 2) r = (23.0f * e - 16.0f * o1[i] + 5.0f * o2[i]) / 12.0f;
+        else r = (55.0f * e - 59.0f * o1[i] + 37.0f * o2[i] - 9.0f * o3[i]) / 24.0f;
+        out[i] = r;
+    }
+}
+extern "C" int advs_plms_combine(const float* eps, const float* eps_uncond, float cfg_scale, const float* eps_next,
+                                 const float* old1, const float* old2, const float* old3, int order, float* guided,
+                                 float* out, size_t n, void* stream) {
+    ADVS_REQUIRE(eps && out && n > 0 && order >= 0, "plms_combine: bad args");
+    ADVS_REQUIRE(order < 1 || old1, "plms_combine: order %d needs old1", order);
+    ADVS_REQUIRE(order < 2 || old2, "plms_combine: order %d needs old2", order);
+    ADVS_REQUIRE(order < 3 || old3, "plms_combine: order %d needs old3", order);
+    const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    plms_combine_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(eps, eps_uncond, cfg_scale, eps_next, old1, old2, old3, order,
+                                                               guided, out, n);
+    ADVS_CHECK_LAUNCH("plms_combine");
+    return ADVS_OK;
+}

@@ -29,7 +29,7 @@ def generate(args):
     Network = network_initializer(network, device)
     diffusion = sample_initializer(args.sample, image_size, device)
     steps = getattr(args, "sample_steps", None)
-    if steps:
+    if steps and hasattr(diffusion, "sample_steps"):
         diffusion = type(diffusion)(sample_steps=steps, img_size=image_size, device=device)
     expand = args.image_size if image_size != args.image_size else None
     dtype = getattr(args, "compute_dtype", "fp32")
@@ -67,7 +67,7 @@ def build_parser():
     p.add_argument("--use_ema", type=bool, default=True)
     p.add_argument("--weight_path", type=str, required=True)
     p.add_argument("--result_path", type=str, default="results/vis")
-    p.add_argument("--sample", type=str, default="ddim")
+    p.add_argument("--sample", type=str, default="ddpm")
     p.add_argument("--network", type=str, default="unet")
     p.add_argument("--act", type=str, default="silu")
     p.add_argument("--num_classes", type=int, default=10)

@@ -5,6 +5,8 @@ import torch
 
 from ..model.networks.unet import UNet
 from ..model.samples.ddim import DDIMDiffusion
+from ..model.samples.ddpm import DDPMDiffusion
+from ..model.samples.plms import PLMSDiffusion
 from .checkpoint import read_ckpt
 
 logger = logging.getLogger(__name__)
@@ -27,10 +29,14 @@ def network_initializer(network, device):
 
 
 def sample_initializer(sample, image_size, device):
-    """utils/initializer.py:158-175.  Only the DDIM sampler is on the hot path so far."""
+    """utils/initializer.py:158-175 (unknown names fall back to ddpm, as in the reference)."""
     if sample == "ddim":
         return DDIMDiffusion(img_size=image_size, device=device)
-    raise NotImplementedError(f"sampler '{sample}' is a next row (SURVEY 8f rank 1); pass --sample ddim")
+    if sample == "plms":
+        return PLMSDiffusion(img_size=image_size, device=device)
+    if sample != "ddpm":
+        logger.warning("[%s]: Setting sample error, we has been automatically set to ddpm.", device)
+    return DDPMDiffusion(img_size=image_size, device=device)
 
 
 def generate_initializer(ckpt_path, args, device):

@@ -159,6 +159,16 @@ int advs_ddim_step(float* x, const float* eps, const float* eps_uncond, float cf
                    const float* noise, const float* coef, const int64_t* tseq, int nsteps,
                    int32_t* step_counter, int64_t* t_out, int b, size_t per_sample, int clip,
                    void* stream);
+/* DDPM ancestral step (model/samples/ddpm.py:74-88): coef[step] = {alpha, alpha_hat, beta};
+ *   x = 1/sqrt(alpha) * (x - ((1-alpha)/sqrt(1-alpha_hat)) * eps') + sqrt(beta) * noise (noise NULL = zeros). */
+int advs_ddpm_step(float* x, const float* eps, const float* eps_uncond, float cfg_scale, const float* noise,
+                   const float* coef, const int64_t* tseq, int nsteps, int32_t* step_counter,
+                   int64_t* t_out, int b, size_t per_sample, void* stream);
+/* PLMS linear-multistep combination of eps predictions (model/samples/plms.py:93-107); `guided` (optional)
+ * receives the CFG-lerped prediction of this step, `out` the combined one.                            */
+int advs_plms_combine(const float* eps, const float* eps_uncond, float cfg_scale, const float* eps_next,
+                      const float* old1, const float* old2, const float* old3, int order, float* guided,
+                      float* out, size_t n, void* stream);
 /* uint8 image = trunc((x+1)*0.5*255) wrapped mod 256 (no clamp: model/samples/ddim.py:97-99),
  * or clamped when clamp != 0.                                                                */
 int advs_to_uint8(const float* x, uint8_t* y, size_t n, int clamp, void* stream);

@@ -194,3 +194,66 @@ def ddim_sample(model_fn, x_T, labels=None, cfg_scale=None, noise_steps=1000, sa
         return x
     x = (x + 1) * 0.5
     return (x * 255).type(torch.uint8)          # wraps mod 256, no clamp (ddim.py:97-99)
+
+
+# --------------------------------------------------------------------------- DDPM / PLMS (model/samples)
+@torch.no_grad()
+def ddpm_sample(model_fn, x_T, noises, labels=None, cfg_scale=None, noise_steps=1000, beta_start=1e-4, beta_end=2e-2,
+                steps=None):
+    """DDPMDiffusion.sample (ddpm.py:62-98) with x_T and the per-step noise injected (``noises[i]`` for i > 1)."""
+    beta = torch.linspace(beta_start, beta_end, noise_steps)
+    alpha = 1.0 - beta
+    ahat = torch.cumprod(alpha, dim=0)
+    x = x_T.clone()
+    n = x.shape[0]
+    ts = list(reversed(range(1, noise_steps)))
+    for i in (ts if steps is None else ts[:steps]):
+        t = (torch.ones(n) * i).long()
+        if labels is None and cfg_scale is None:
+            eps = model_fn(x, t, None)
+        else:
+            eps = model_fn(x, t, labels)
+            if cfg_scale > 0:
+                eps = torch.lerp(model_fn(x, t, None), eps, cfg_scale)
+        a, ah, b = alpha[t][:, None, None, None], ahat[t][:, None, None, None], beta[t][:, None, None, None]
+        noise = noises[i] if i > 1 else torch.zeros_like(x)
+        x = 1 / torch.sqrt(a) * (x - ((1 - a) / (torch.sqrt(1 - ah))) * eps) + torch.sqrt(b) * noise
+    x = (x.clamp(-1, 1) + 1) / 2
+    return (x * 255).type(torch.uint8)
+
+
+@torch.no_grad()
+def plms_sample(model_fn, x_T, labels=None, cfg_scale=None, noise_steps=1000, sample_steps=500, to_uint8=True):
+    """PLMSDiffusion.sample (plms.py:63-121), eta = 0."""
+    ah = alpha_hat(noise_steps)
+    x = x_T.clone()
+    n = x.shape[0]
+    old = []
+    for i, p_i in time_pairs(noise_steps, sample_steps):
+        t, p_t = (torch.ones(n) * i).long(), (torch.ones(n) * p_i).long()
+        a_t, a_p = ah[t][:, None, None, None], ah[p_t][:, None, None, None]
+        if labels is None and cfg_scale is None:
+            eps = model_fn(x, t, None)
+        else:
+            eps = model_fn(x, t, labels)
+            if cfg_scale > 0:
+                eps = torch.lerp(model_fn(x, t, None), eps, cfg_scale)
+        c2 = torch.sqrt((1 - a_p))
+        if len(old) == 0:
+            x0 = torch.clamp((x - (eps * torch.sqrt((1 - a_t)))) / torch.sqrt(a_t), -1, 1)
+            p_x = torch.sqrt(a_p) * x0 + c2 * eps
+            nxt = model_fn(p_x, p_t, None if (labels is None and cfg_scale is None) else labels)
+            prime = (eps + nxt) / 2
+        elif len(old) == 1:
+            prime = (3 * eps - old[-1]) / 2
+        elif len(old) == 2:
+            prime = (23 * eps - 16 * old[-1] + 5 * old[-2]) / 12
+        else:
+            prime = (55 * eps - 59 * old[-1] + 37 * old[-2] - 9 * old[-3]) / 24
+        x0 = torch.clamp((x - (prime * torch.sqrt((1 - a_t)))) / torch.sqrt(a_t), -1, 1)
+        x = torch.sqrt(a_p) * x0 + c2 * prime
+        old.append(eps)
+    if not to_uint8:
+        return x
+    x = (x + 1) * 0.5
+    return (x * 255).type(torch.uint8)

@@ -139,7 +139,37 @@ def gen_lineage_a():
          time_pairs_500=np.array([[int(a), int(b)] for a, b in d500.time_step]))
 
 
-GROUPS = {"lineage_b": gen_lineage_b, "lineage_a": gen_lineage_a}
+# --------------------------------------------------------------------------- DDPM / PLMS samplers
+def gen_samplers():
+    from model.networks.unet import UNet
+    import model.samples.ddpm as ddpm_mod
+    import model.samples.plms as plms_mod
+    ddpm_mod.tqdm = lambda it, **k: it
+    plms_mod.tqdm = lambda it, **k: it
+    torch.manual_seed(1)
+    net = UNet(num_classes=37, device="cpu", image_size=64, act="silu").eval()
+    keys, dg = digest(net.state_dict())
+    labels = torch.tensor([5, 30])
+    arrs = dict(sd_keys=keys, sd_digest=dg, labels=labels.numpy())
+    # DDPM: 12 noise steps -> 11 ancestral steps; the RNG stream is x_T then one randn per step with i > 1
+    d = ddpm_mod.DDPMDiffusion(noise_steps=12, img_size=64, device="cpu")
+    torch.manual_seed(777)
+    arrs["ddpm_xT"] = torch.randn((2, 3, 64, 64)).numpy()
+    arrs["ddpm_noise"] = np.stack([torch.randn((2, 3, 64, 64)).numpy() for _ in range(10)])     # i = 11 .. 2
+    torch.manual_seed(777)
+    arrs["ddpm_cfg3"] = d.sample(net, 2, labels=labels, cfg_scale=3, save_path=None).numpy()
+    net.eval()
+    p = plms_mod.PLMSDiffusion(sample_steps=8, img_size=64, device="cpu")
+    torch.manual_seed(888)
+    arrs["plms_xT"] = torch.randn((2, 3, 64, 64)).numpy()
+    torch.manual_seed(888)
+    arrs["plms_cfg3"] = p.sample(net, 2, labels=labels, cfg_scale=3, save_path=None).numpy()
+    torch.manual_seed(888)
+    arrs["plms_uncond"] = p.sample(net, 2, save_path=None).numpy()
+    save("lineage_a_samplers.npz", **arrs)
+
+
+GROUPS = {"lineage_b": gen_lineage_b, "lineage_a": gen_lineage_a, "samplers": gen_samplers}
 
 if __name__ == "__main__":
     for g in (sys.argv[1:] or list(GROUPS)):

@@ -79,3 +79,32 @@ def test_wrong_image_size_is_rejected():
     net = make("silu")
     with pytest.raises(ValueError):
         net(torch.zeros(1, 3, 128, 128, device="cuda"), torch.zeros(1, dtype=torch.long, device="cuda"))
+
+
+def test_ddpm_and_plms_vs_golden(golden):
+    """DDPM (injected per-step noise) and PLMS (cfg and unconditional) uint8 outputs vs the reference's."""
+    from advshadow_amd.model.samples.ddpm import DDPMDiffusion
+    from advshadow_amd.model.samples.plms import PLMSDiffusion
+    g = golden("lineage_a_samplers.npz")
+    net = make("silu")
+    labels = torch.from_numpy(g["labels"]).cuda()
+    noises = {i: torch.from_numpy(g["ddpm_noise"][11 - i]) for i in range(2, 12)}
+    d = DDPMDiffusion(noise_steps=12, img_size=64, device="cuda")
+    out = d.sample(net, 2, labels=labels, cfg_scale=3, x_T=torch.from_numpy(g["ddpm_xT"]),
+                   noise_fn=lambda i, shape: noises[i])
+    diff = wrap_diff(out.cpu().numpy(), g["ddpm_cfg3"])
+    assert out.dtype == torch.uint8 and diff.max() <= 1 and (diff > 0).mean() < 0.01, (diff.max(), (diff > 0).mean())
+    p = PLMSDiffusion(sample_steps=8, img_size=64, device="cuda")
+    out = p.sample(net, 2, labels=labels, cfg_scale=3, x_T=torch.from_numpy(g["plms_xT"]))
+    diff = wrap_diff(out.cpu().numpy(), g["plms_cfg3"])
+    assert diff.max() <= 1 and (diff > 0).mean() < 0.01, (diff.max(), (diff > 0).mean())
+    out = p.sample(net, 2, x_T=torch.from_numpy(g["plms_xT"]))
+    diff = wrap_diff(out.cpu().numpy(), g["plms_uncond"])
+    assert diff.max() <= 1 and (diff > 0).mean() < 0.01
+
+
+def test_ddpm_device_noise_runs():
+    from advshadow_amd.model.samples.ddpm import DDPMDiffusion
+    net = make("silu")
+    out = DDPMDiffusion(noise_steps=6, img_size=64, device="cuda").sample(net, 1)
+    assert out.shape == (1, 3, 64, 64) and out.dtype == torch.uint8

@@ -55,3 +55,20 @@ def test_ddim_sample_matches_reference(golden):
     out = oa.ddim_sample(fn, xT, sample_steps=10).numpy()
     d = wrap_diff(out, g["sample_uncond"])
     assert d.max() <= 1 and (d > 0).mean() < 0.01
+
+
+def test_ddpm_and_plms_match_reference(golden):
+    g = golden("lineage_a_samplers.npz")
+    sd = oa.init_state_dict(1, num_classes=37, act="silu")
+    fn = lambda x, t, y: oa.unet_forward(sd, x, t, y)
+    labels = torch.from_numpy(g["labels"])
+    noises = {i: torch.from_numpy(g["ddpm_noise"][11 - i]) for i in range(2, 12)}
+    out = oa.ddpm_sample(fn, torch.from_numpy(g["ddpm_xT"]), noises, labels=labels, cfg_scale=3, noise_steps=12).numpy()
+    d = wrap_diff(out, g["ddpm_cfg3"])
+    assert d.max() <= 1 and (d > 0).mean() < 0.01
+    out = oa.plms_sample(fn, torch.from_numpy(g["plms_xT"]), labels=labels, cfg_scale=3, sample_steps=8).numpy()
+    d = wrap_diff(out, g["plms_cfg3"])
+    assert d.max() <= 1 and (d > 0).mean() < 0.01
+    out = oa.plms_sample(fn, torch.from_numpy(g["plms_xT"]), sample_steps=8).numpy()
+    d = wrap_diff(out, g["plms_uncond"])
+    assert d.max() <= 1 and (d > 0).mean() < 0.01
