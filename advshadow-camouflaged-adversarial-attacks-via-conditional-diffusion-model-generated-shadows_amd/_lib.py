@@ -32,7 +32,7 @@ SIGNATURES = {
     "advs_nhwc_to_nchw_f32": [vp, vp, i32, i32, i32, i32, i32, vp],
     "advs_conv2d": [C.POINTER(ConvArgs), vp],
     "advs_conv_set_tile": [i32],
-    "advs_conv_pick_tile": [C.c_longlong, i32],
+    "advs_conv_resolve_tile": [C.POINTER(ConvArgs)],
     "advs_conv_tile_rows": [i32],
     "advs_groupnorm_stats": [vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "advs_conv3x3_first": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],

@@ -1,0 +1,155 @@
+// Shared pieces of the implicit-GEMM convolution kernels (conv_igemm.hip, conv_halo.hip).
+#pragma once
+#include "common.h"
+
+#define SLAB 128                 // bytes of K per row per step
+
+// Division by a launch-invariant divisor (Granlund-Montgomery): q = (umulhi(n, m) + n) >> s, exact
+// for n < 2^31.  Replaces ~35-instruction integer divides in the tile prologue / epilogue.
+struct FastDiv {
+    unsigned d, m, s;
+    __host__ void init(unsigned dd) {
+        d = dd; s = 0;
+        while ((1ull << s) < dd) ++s;
+        m = (unsigned)(((1ull << 32) * ((1ull << s) - dd)) / dd + 1);
+    }
+    __device__ __forceinline__ unsigned div(unsigned n) const { return (__umulhi(n, m) + n) >> s; }
+};
+
+struct ConvKP {
+    const char* x1; const char* x2; const char* w;
+    const char* e1; const char* e2;   // extra 1x1 operand (two concat sources) appended to K, or null
+    int E1, E2; unsigned e1_bytes, e2_bytes;
+    const float* bias; const float* temb; const char* res; char* y;
+    float* stats;                // [ceil(M/WM)][Cout][2] per-channel (sum, sum of squares) of y, or null
+    unsigned x1_bytes, x2_bytes, w_bytes;
+    int B, H, W, C1, C2, Cout;
+    int R, stride, pad, ups;
+    int Ho, Wo, M, K;            // K in elements
+    int act, temb_stride;
+    int nMt, nNt;
+    FastDiv dHoWo, dWo;
+};
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+#define OOB_OFFSET 0xF0000000u   // > every num_records we accept: the bounds check returns zeros
+
+__device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, char* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)lds_wave_base, 16, voff, soff, 0, 0);
+}
+
+template <typename T> struct Mma;
+template <> struct Mma<BF16> {
+    static constexpr int ESZ = 2;
+    // one 16-byte fragment per operand = K of 16 (two lane halves x 8)
+    __device__ static __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    static constexpr int ESZ = 4;
+    // 16 bytes = 4 floats per lane half; float j of both halves forms one K=2 step
+    __device__ static __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[j]), __uint_as_float(b[j]), c, 0, 0, 0);
+    }
+};
+
+
+// ---- epilogue shared by both kernels.  C/D layout of a 32x32 MFMA tile: col = lane&31,
+// row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  Per 32-row strip the wave parks its 32 x WN accumulators in
+// a private LDS patch (f32, row-major) and re-reads it one 16-byte output vector per lane, so bias /
+// temb / residual are read and y is written along the channel axis in whole 128-byte lines.
+//   row_to_m(lr): output pixel index of the wave's local row lr (0 .. TM*32), or -1 when out of range
+//   temb_b: batch index when every row of the wave shares it (temb folded into the bias), -1 = per row
+//   rb: row-block index for the epilogue statistics, -1 = this wave writes none
+template <typename T, int WN, int TM, int TN, typename RowMap>
+__device__ __forceinline__ void conv_epilogue(const ConvKP& p, f32x16 (&acc)[TM][TN], float* patch, int lane,
+                                              int ncol0, RowMap row_to_m, int temb_b, int rb) {
+    constexpr int VEC = 16 / Mma<T>::ESZ;
+    constexpr int LPR = WN / VEC;                 // lanes per patch row
+    constexpr int RPI = 64 / LPR;                 // rows per wave-instruction
+    const int l31 = lane & 31, lh = lane >> 5;
+    T* y = (T*)p.y;
+    const T* res = (const T*)p.res;
+    const int prow = lane / LPR, pcv = lane - prow * LPR;
+    const int n = ncol0 + pcv * VEC;
+    const bool n_ok = n < p.Cout;                 // Cout is a multiple of VEC
+    float bias[VEC], ssum[VEC], ssq[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { bias[e] = (p.bias && n_ok) ? p.bias[n + e] : 0.f; ssum[e] = 0.f; ssq[e] = 0.f; }
+    const bool temb_rowwise = p.temb && temb_b < 0;
+    if (p.temb && temb_b >= 0 && n_ok) {
+        const float* tp = p.temb + (size_t)temb_b * p.temb_stride + n;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) bias[e] += tp[e];
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * WN + j * 32 + l31] = acc[i][j][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int it = 0; it < 32 / RPI; ++it) {
+            const int row = it * RPI + prow;
+            const int m = row_to_m(i * 32 + row);
+            float v[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; e += 4) {
+                const f32x4 t = *(const f32x4*)(patch + row * WN + pcv * VEC + e);
+                v[e] = t[0]; v[e + 1] = t[1]; v[e + 2] = t[2]; v[e + 3] = t[3];
+            }
+            if (m >= 0 && n_ok) {
+                const size_t o = (size_t)m * p.Cout + n;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v[e] += bias[e];
+                if (temb_rowwise) {
+                    const float* tp = p.temb + (size_t)p.dHoWo.div((unsigned)m) * p.temb_stride + n;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) v[e] += tp[e];
+                }
+                if (res) {
+                    float rv[VEC];
+                    unpack16<T>(*(const u32x4*)(res + o), rv);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) v[e] += rv[e];
+                }
+                if (p.act != ADVS_ACT_NONE) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) v[e] = apply_act(v[e], p.act);
+                }
+                const u32x4 packed = pack16<T>(v);
+                *(u32x4*)(y + o) = packed;
+                if (p.stats) {                    // statistics of the values as stored (after rounding)
+                    float sv[VEC];
+                    unpack16<T>(packed, sv);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) { ssum[e] += sv[e]; ssq[e] = fmaf(sv[e], sv[e], ssq[e]); }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (p.stats) {
+        // fold the RPI row-lanes that share a channel vector (fixed butterfly order), lanes 0..LPR-1 store
+#pragma unroll
+        for (int o = LPR; o < 64; o <<= 1)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { ssum[e] += __shfl_xor(ssum[e], o); ssq[e] += __shfl_xor(ssq[e], o); }
+        if (prow == 0 && n_ok && rb >= 0) {
+            float* sp = p.stats + ((size_t)rb * p.Cout + n) * 2;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { sp[2 * e] = ssum[e]; sp[2 * e + 1] = ssq[e]; }
+        }
+    }
+}

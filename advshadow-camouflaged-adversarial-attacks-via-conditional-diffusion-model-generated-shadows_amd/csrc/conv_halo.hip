@@ -1,0 +1,219 @@
+// 3x3 stride-1 convolution as an implicit GEMM over a HALO tile (the hot shape of the eps-predictor:
+// every ResidualBlock conv, diff_model.py:73,86).
+//
+// conv_igemm.hip re-fetches the A rows of a tile once per filter tap (9x).  Here a workgroup owns a
+// 16x16 block of output pixels of ONE image and stages, per 128-byte channel slab, the 18x18 halo of
+// input pixels ONCE (41 KiB); the nine taps then read shifted windows of that patch straight out of
+// LDS.  Only the weights (16 KiB per tap) still stream per tap.  Per (slab, 9 taps) the workgroup moves
+// 41 + 144 KiB instead of 9 x (32 + 16) KiB, and a wave issues ~2.7 instead of 8 LDS-DMA
+// instructions per 16 MFMAs, which is what bounds the per-tap kernel (MI355X_MICROARCH: an LDS-DMA
+// piece costs 60-185 issue cycles).
+//
+// Workgroup: 8 waves (4 along pixels x 2 along channels), each a 64x64 block of 32x32 MFMA tiles;
+// output tile 256 pixels x 128 channels.  LDS: A halo double-buffered per slab (2 x 42 KiB), B ring of
+// three 16 KiB stages with ONE barrier per tap.  The nine taps are unrolled so every counted
+// `s_waitcnt vmcnt(N)` is a literal: at the top of tap t the oldest outstanding group must be this
+// tap's weights, and the only younger traffic is next tap's weights plus at most two halo pieces.
+// Rows of 128 B are XOR-swizzled by (halo pixel >> 1) & 7 on the source address (see conv_igemm.hip).
+#include "conv_common.h"
+#include <type_traits>
+
+#define HT 16                    // output tile edge
+#define HWID 18                  // halo edge
+#define HPIX (HWID * HWID)       // 324 halo pixels
+#define HPIECES 41               // ceil(324 / 8) DMA pieces of 8 pixels x 128 B
+#define HA_STAGE (42 * 1024)     // 41 pieces + one scratch piece for the waves' padding DMAs
+#define HB_STAGE (128 * SLAB)    // 16 KiB: 128 output channels x 128 B
+#define HNP 6                    // A pieces per wave per slab (8 waves x 6 >= 41)
+
+template <typename T>
+__global__ void __launch_bounds__(512)
+conv3x3_halo_kernel(const ConvKP p) {
+    constexpr int ESZ = Mma<T>::ESZ;
+    constexpr int BKE = SLAB / ESZ;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];   // [2][HA_STAGE] then [3][HB_STAGE]
+    char* sA = smem;
+    char* sB = smem + 2 * HA_STAGE;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5, chunk = lane & 7;
+
+    // ---- workgroup -> (image, pixel tile, channel tile); channel tiles of one pixel tile are neighbours
+    // on one XCD so the halo is re-read from that XCD's L2
+    const int tiles_x = p.W / HT, tpi = tiles_x * (p.H / HT);
+    const int nblk = p.nMt * p.nNt;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tl = bid / p.nNt, nt = bid - tl * p.nNt;
+    const int b = tl / tpi, ti = tl - b * tpi;
+    const int ty = ti / tiles_x, tx = ti - ty * tiles_x;
+    const int y0 = ty * HT, x0 = tx * HT, n0 = nt * 128;
+
+    // ---- staging geometry.  Halo piece q covers halo pixels 8q .. 8q+7 (row-major in the 18x18 patch).
+    int apix[HNP];                                   // source pixel index, -1 = outside the image / patch
+    unsigned acsw[HNP], a_voff[HNP], a_dst[HNP], b_voff[2];
+#pragma unroll
+    for (int j = 0; j < HNP; ++j) {
+        const int q = wave + 8 * j;
+        const int hidx = q * 8 + (lane >> 3);
+        const int hy = hidx / HWID, hx = hidx - hy * HWID;
+        const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+        const bool inb = q < HPIECES && hidx < HPIX && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+        apix[j] = inb ? (b * p.H + gy) * p.W + gx : -1;
+        acsw[j] = (unsigned)((chunk ^ ((hidx >> 1) & 7)) << 4);
+        a_dst[j] = (unsigned)(q < HPIECES ? q : HPIECES) * 1024u;       // padding DMAs land in the scratch piece
+        a_voff[j] = OOB_OFFSET;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (wave * 2 + j) * 8 + (lane >> 3);
+        const int n = n0 + row;
+        b_voff[j] = (n < p.Cout) ? (unsigned)n * (unsigned)p.K * ESZ + ((chunk ^ ((row >> 1) & 7)) << 4) : OOB_OFFSET;
+    }
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x1, 0, p.x1_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x2 ? p.x2 : p.x1), 0, p.x2_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+
+    const int Cin = p.C1 + p.C2;
+    const int ncs1 = p.C1 / BKE, nunits = Cin / BKE;   // one unit = one 128-byte channel slab (all 9 taps)
+    const int total_it = nunits * 9;
+
+    auto set_a_voff = [&](int unit) {                // byte offsets of the halo pixels in `unit`'s source
+        const unsigned cs = (unsigned)(unit < ncs1 ? p.C1 : p.C2) * ESZ;
+#pragma unroll
+        for (int j = 0; j < HNP; ++j) a_voff[j] = apix[j] >= 0 ? (unsigned)apix[j] * cs + acsw[j] : OOB_OFFSET;
+    };
+    auto issue_A = [&](int unit, int j) {
+        char* dst = sA + (unit & 1) * HA_STAGE + a_dst[j];
+        if (unit < ncs1) blds16(rs1, a_voff[j], (unsigned)unit * SLAB, dst);
+        else blds16(rs2, a_voff[j], (unsigned)(unit - ncs1) * SLAB, dst);
+    };
+    auto issue_B = [&](int unit, int t, int j) {     // weights of (slab unit, tap t): K offset t*Cin + unit*BKE
+        const unsigned woff = (unsigned)(t * Cin + unit * BKE) * ESZ;
+        blds16(rsw, b_voff[j], woff, sB + (t % 3) * HB_STAGE + (wave * 2 + j) * 1024);
+    };
+
+    // ---- fragment geometry: wave (wr, wc) owns tile rows 4wr..4wr+3 (x16 px) and channels wc*64..+63
+    const int wr = wave >> 1, wc = wave & 1;
+    int hidx0[2], b_off[2], b_sw[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        hidx0[i] = (4 * wr + 2 * i + (l31 >> 4)) * HWID + (l31 & 15);
+        const int rb = wc * 64 + i * 32 + l31;
+        b_off[i] = rb * SLAB; b_sw[i] = (rb >> 1) & 7;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- prologue: halo of slab 0, weights of taps 0 and 1
+    set_a_voff(0);
+#pragma unroll
+    for (int j = 0; j < HNP; ++j) issue_A(0, j);
+    issue_B(0, 0, 0); issue_B(0, 0, 1);
+    issue_B(0, 1, 0); issue_B(0, 1, 1);
+
+    for (int unit = 0; unit < nunits; ++unit) {
+        const bool hn = unit + 1 < nunits;           // a next slab exists: its halo is prefetched during this one
+        if (hn && (unit + 1 == ncs1 || unit == 0)) set_a_voff(unit + 1);
+        const char* la = sA + (unit & 1) * HA_STAGE;
+        auto tap = [&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            // Outstanding, oldest first: W(t) [+halo piece t-2], W(t+1) [+halo piece t-1].  Wait for W(t).
+            constexpr int nA = ((t - 2 >= 0 && t - 2 < HNP) ? 1 : 0) + ((t - 1 >= 0 && t - 1 < HNP) ? 1 : 0);
+            if (t < 8) {
+                if (hn) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + nA) : "memory");
+                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            } else {
+                if (hn) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            // (unit, t+2) wraps into the next slab for t = 7, 8
+            const bool wb = t < 7 || hn;
+            const int u2 = t < 7 ? unit : unit + 1, t2 = t < 7 ? t + 2 : t - 7;
+            const int r = t / 3, s = t % 3;
+            const char* lb = sB + (t % 3) * HB_STAGE;
+            int a_row[2], a_sw[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int hidx = hidx0[i] + r * HWID + s;
+                a_row[i] = hidx * SLAB; a_sw[i] = (hidx >> 1) & 7;
+            }
+            u32x4 af[2][2], bf[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[0][i] = *(const u32x4*)(la + a_row[i] + (((0 + lh) ^ a_sw[i]) << 4));
+                bf[0][i] = *(const u32x4*)(lb + b_off[i] + (((0 + lh) ^ b_sw[i]) << 4));
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int cur = ks & 1, nxt = cur ^ 1;
+                if (ks < 3) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        af[nxt][i] = *(const u32x4*)(la + a_row[i] + (((2 * (ks + 1) + lh) ^ a_sw[i]) << 4));
+                        bf[nxt][i] = *(const u32x4*)(lb + b_off[i] + (((2 * (ks + 1) + lh) ^ b_sw[i]) << 4));
+                    }
+                }
+                // this tap's share of the DMA issue, spread between the MFMA groups (weights first)
+                if (ks == 0 && wb) issue_B(u2, t2, 0);
+                if (ks == 1 && wb) issue_B(u2, t2, 1);
+                if (ks == 2 && hn && t < HNP) issue_A(unit + 1, t);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) Mma<T>::run(af[cur][i], bf[cur][j], acc[i][j]);
+                __builtin_amdgcn_s_setprio(0);
+            }
+        };
+        tap(std::integral_constant<int, 0>{}); tap(std::integral_constant<int, 1>{}); tap(std::integral_constant<int, 2>{});
+        tap(std::integral_constant<int, 3>{}); tap(std::integral_constant<int, 4>{}); tap(std::integral_constant<int, 5>{});
+        tap(std::integral_constant<int, 6>{}); tap(std::integral_constant<int, 7>{}); tap(std::integral_constant<int, 8>{});
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                    // every wave is done reading before the patches reuse LDS
+
+    conv_epilogue<T, 64, 2, 2>(p, acc, (float*)smem + wave * (32 * 64), lane, n0 + wc * 64,
+                               [&](int lr) { return (b * p.H + y0 + 4 * wr + (lr >> 4)) * p.W + x0 + (lr & 15); },
+                               p.temb ? b : -1, tl * 4 + wr);
+}
+
+// Can this launch use the halo kernel?  3x3, stride 1, pad 1, no upsample, no extra operand, image a
+// multiple of 16 pixels both ways.
+bool conv_halo_eligible(const ConvKP& p) {
+    return p.R == 3 && p.stride == 1 && p.pad == 1 && p.ups == 0 && p.e1 == nullptr &&
+           p.H % HT == 0 && p.W % HT == 0 && p.Ho == p.H && p.Wo == p.W;
+}
+
+template <typename T>
+static int halo_launch(ConvKP& p, hipStream_t st) {
+    constexpr int lds = 2 * HA_STAGE + 3 * HB_STAGE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        ADVS_HIP(hipFuncSetAttribute((const void*)conv3x3_halo_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    p.nMt = p.B * (p.H / HT) * (p.W / HT);
+    p.nNt = cdiv(p.Cout, 128);
+    conv3x3_halo_kernel<T><<<p.nMt * p.nNt, 512, lds, st>>>(p);
+    ADVS_CHECK_LAUNCH("conv3x3_halo");
+    return ADVS_OK;
+}
+
+int conv_halo_dispatch(ConvKP& p, int dtype, hipStream_t st) {
+    ADVS_REQUIRE(conv_halo_eligible(p), "conv2d: tile 10 (halo kernel) needs 3x3 stride 1 pad 1, no upsample / extra operand, H and W multiples of 16");
+    if (dtype == ADVS_BF16) return halo_launch<BF16>(p, st);
+    return halo_launch<float>(p, st);
+}

@@ -27,63 +27,7 @@
 // stored values: the GroupNorm that consumes y then needs no statistics pass over the tensor.
 //
 // Roofline: MFMA-bound.  Algorithmic FLOPs per launch = 2*M*N*K.
-#include "common.h"
-
-#define SLAB 128                 // bytes of K per row per step
-
-// Division by a launch-invariant divisor (Granlund-Montgomery): q = (umulhi(n, m) + n) >> s, exact
-// for n < 2^31.  Replaces ~35-instruction integer divides in the tile prologue / epilogue.
-struct FastDiv {
-    unsigned d, m, s;
-    __host__ void init(unsigned dd) {
-        d = dd; s = 0;
-        while ((1ull << s) < dd) ++s;
-        m = (unsigned)(((1ull << 32) * ((1ull << s) - dd)) / dd + 1);
-    }
-    __device__ __forceinline__ unsigned div(unsigned n) const { return (__umulhi(n, m) + n) >> s; }
-};
-
-struct ConvKP {
-    const char* x1; const char* x2; const char* w;
-    const char* e1; const char* e2;   // extra 1x1 operand (two concat sources) appended to K, or null
-    int E1, E2; unsigned e1_bytes, e2_bytes;
-    const float* bias; const float* temb; const char* res; char* y;
-    float* stats;                // [ceil(M/WM)][Cout][2] per-channel (sum, sum of squares) of y, or null
-    unsigned x1_bytes, x2_bytes, w_bytes;
-    int B, H, W, C1, C2, Cout;
-    int R, stride, pad, ups;
-    int Ho, Wo, M, K;            // K in elements
-    int act, temb_stride;
-    int nMt, nNt;
-    FastDiv dHoWo, dWo;
-};
-
-typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(1))) void glb_void;
-
-#define OOB_OFFSET 0xF0000000u   // > every num_records we accept: the bounds check returns zeros
-
-__device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, char* lds_wave_base) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)lds_wave_base, 16, voff, soff, 0, 0);
-}
-
-template <typename T> struct Mma;
-template <> struct Mma<BF16> {
-    static constexpr int ESZ = 2;
-    // one 16-byte fragment per operand = K of 16 (two lane halves x 8)
-    __device__ static __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) {
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-    }
-};
-template <> struct Mma<float> {
-    static constexpr int ESZ = 4;
-    // 16 bytes = 4 floats per lane half; float j of both halves forms one K=2 step
-    __device__ static __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[j]), __uint_as_float(b[j]), c, 0, 0, 0);
-    }
-};
+#include "conv_common.h"
 
 template <typename T, int BM, int BN, int WM, int WN, int NSTAGE, bool ILV>
 __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
@@ -340,93 +284,13 @@ conv_igemm_kernel(const ConvKP p) {
         __builtin_amdgcn_s_barrier();                                // all reads done before the patches reuse LDS
     }
 
-    // ---- epilogue.  C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
-    // Per 32-row strip the wave parks its 32 x WN accumulators in a private LDS patch
-    // (f32, row-major) and re-reads it one 16-byte output vector per lane.
-    constexpr int LPR = WN / VEC;                 // lanes per patch row
-    constexpr int RPI = 64 / LPR;                 // rows per wave-instruction
-    float* patch = (float*)smem + wave * (32 * WN);
-    T* y = (T*)p.y;
-    const T* res = (const T*)p.res;
-    const int prow = lane / LPR, pcv = lane - prow * LPR;
-    const int n = n0 + wc * WN + pcv * VEC;
-    const bool n_ok = n < p.Cout;                 // Cout is a multiple of VEC
-    float bias[VEC], ssum[VEC], ssq[VEC];
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) { bias[e] = (p.bias && n_ok) ? p.bias[n + e] : 0.f; ssum[e] = 0.f; ssq[e] = 0.f; }
-    // when a wave's WM rows lie inside one image its temb row is one vector: fold it into the bias
-    const bool temb_rowwise = p.temb && (HoWo % WM != 0);
-    if (p.temb && !temb_rowwise && n_ok && m0 + wr * WM < p.M) {
-        const float* tp = p.temb + (size_t)p.dHoWo.div((unsigned)(m0 + wr * WM)) * p.temb_stride + n;
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) bias[e] += tp[e];
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * WN + j * 32 + l31] = acc[i][j][r];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-        for (int it = 0; it < 32 / RPI; ++it) {
-            const int row = it * RPI + prow;
-            const int m = m0 + wr * WM + i * 32 + row;
-            float v[VEC];
-#pragma unroll
-            for (int e = 0; e < VEC; e += 4) {
-                const f32x4 t = *(const f32x4*)(patch + row * WN + pcv * VEC + e);
-                v[e] = t[0]; v[e + 1] = t[1]; v[e + 2] = t[2]; v[e + 3] = t[3];
-            }
-            if (m < p.M && n_ok) {
-                const size_t o = (size_t)m * p.Cout + n;
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) v[e] += bias[e];
-                if (temb_rowwise) {
-                    const float* tp = p.temb + (size_t)p.dHoWo.div((unsigned)m) * p.temb_stride + n;
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) v[e] += tp[e];
-                }
-                if (res) {
-                    float rv[VEC];
-                    unpack16<T>(*(const u32x4*)(res + o), rv);
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) v[e] += rv[e];
-                }
-                if (p.act != ADVS_ACT_NONE) {
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) v[e] = apply_act(v[e], p.act);
-                }
-                const u32x4 packed = pack16<T>(v);
-                *(u32x4*)(y + o) = packed;
-                if (p.stats) {                    // statistics of the values as stored (after rounding)
-                    float sv[VEC];
-                    unpack16<T>(packed, sv);
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) { ssum[e] += sv[e]; ssq[e] = fmaf(sv[e], sv[e], ssq[e]); }
-                }
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-    if (p.stats) {
-        // fold the RPI row-lanes that share a channel vector (fixed butterfly order), lanes 0..LPR-1 store
-#pragma unroll
-        for (int o = LPR; o < 64; o <<= 1)
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) { ssum[e] += __shfl_xor(ssum[e], o); ssq[e] += __shfl_xor(ssq[e], o); }
-        if (prow == 0 && n_ok && m0 + wr * WM < p.M) {          // row blocks past M do not exist
-            const int rb = (m0 + wr * WM) / WM;
-            float* sp = p.stats + ((size_t)rb * p.Cout + n) * 2;
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) { sp[2 * e] = ssum[e]; sp[2 * e + 1] = ssq[e]; }
-        }
-    }
+    // ---- epilogue (conv_common.h)
+    const int mw = m0 + wr * WM;                               // first row of this wave
+    const bool wave_live = mw < p.M;
+    const int temb_b = (p.temb && HoWo % WM == 0 && wave_live) ? (int)p.dHoWo.div((unsigned)mw) : -1;
+    conv_epilogue<T, WN, TM, TN>(p, acc, (float*)smem + wave * (32 * WN), lane, n0 + wc * WN,
+                                 [&](int lr) { const int m = mw + lr; return m < p.M ? m : -1; },
+                                 temb_b, wave_live ? mw / WM : -1);
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int NSTAGE = 2, bool ILV = false>
@@ -446,6 +310,8 @@ static int conv_launch(ConvKP& p, hipStream_t st) {
 }
 
 static int pick_tile(long long M, int cout);
+bool conv_halo_eligible(const ConvKP& p);
+int conv_halo_dispatch(ConvKP& p, int dtype, hipStream_t st);
 
 template <typename T>
 static int conv_dispatch(ConvKP& p, int tile, hipStream_t st) {
@@ -477,10 +343,25 @@ static int pick_tile(long long M, int cout) {
     const long long blocks256 = (long long)cdiv(M, 256) * cdiv(cout, 256);
     return (cout % 256 == 0 && blocks256 >= 384) ? 4 : 1;
 }
-/* tile id advs_conv2d would choose for an M x cout output, and the row-block height (WM) of a tile id */
-extern "C" int advs_conv_pick_tile(long long m, int cout) { return g_tile_override ? g_tile_override : pick_tile(m, cout); }
+// the 16x16-pixel halo kernel wins wherever it applies (3x3, stride 1, no upsample / extra operand, image a
+// multiple of 16: +15..30 % over the per-tap tiles on every such layer of the eps-predictor, tools/tune_conv.py)
+static int resolve_tile(const advs_conv_args* a, long long M) {
+    if (g_tile_override) return g_tile_override;
+    if (a->tile) return a->tile;
+    if (a->ksize == 3 && a->stride == 1 && a->pad == 1 && !a->upsample && !a->e1 && a->h % 16 == 0 && a->w_ % 16 == 0)
+        return 10;
+    return pick_tile(M, a->cout);
+}
+/* tile id advs_conv2d will use for this descriptor, and the row-block height (rows per stats entry) of a tile id */
+extern "C" int advs_conv_resolve_tile(const advs_conv_args* a) {
+    if (!a) return 0;
+    const int ups = a->upsample ? 1 : 0;
+    const long long ho = (((long long)a->h << ups) + 2 * a->pad - a->ksize) / a->stride + 1;
+    const long long wo = (((long long)a->w_ << ups) + 2 * a->pad - a->ksize) / a->stride + 1;
+    return resolve_tile(a, (long long)a->b * ho * wo);
+}
 extern "C" int advs_conv_tile_rows(int tile) {
-    switch (tile) { case 1: case 2: case 5: case 6: case 8: return 64; case 3: case 4: case 7: case 9: return 128; default: return 0; }
+    switch (tile) { case 1: case 2: case 5: case 6: case 8: case 10: return 64; case 3: case 4: case 7: case 9: return 128; default: return 0; }
 }
 
 extern "C" int advs_conv2d(const advs_conv_args* a, void* stream) {
@@ -523,14 +404,19 @@ extern "C" int advs_conv2d(const advs_conv_args* a, void* stream) {
     p.x1_bytes = (unsigned)x1b; p.x2_bytes = (unsigned)(a->x2 ? x2b : x1b); p.w_bytes = (unsigned)wb;
     p.act = a->act; p.temb_stride = a->temb_stride > 0 ? a->temb_stride : a->cout;
     p.dHoWo.init((unsigned)(p.Ho * p.Wo)); p.dWo.init((unsigned)p.Wo);
-    const int tile = g_tile_override ? g_tile_override : a->tile;
+    int tile = resolve_tile(a, M);
+    if (tile == 10 && !conv_halo_eligible(p)) {
+        ADVS_REQUIRE(g_tile_override != 0, "conv2d: tile 10 (halo kernel) needs 3x3 stride 1 pad 1, no upsample / extra operand, H and W multiples of 16");
+        tile = pick_tile(M, a->cout);                       // tuning override on a shape the halo kernel cannot take
+    }
     if (p.stats) {
-        const int wm = advs_conv_tile_rows(tile ? tile : pick_tile(p.M, p.Cout));
+        const int wm = advs_conv_tile_rows(tile);
         ADVS_REQUIRE(wm > 0 && (p.Ho * p.Wo) % wm == 0, "conv2d: stats need Ho*Wo (%d) to be a multiple of the tile's row block (%d)",
                      p.Ho * p.Wo, wm);
         if (g_tile_override && a->stats_rows != wm) p.stats = nullptr;   // tuning runs: buffer sized for another tile
         else ADVS_REQUIRE(a->stats_rows == wm, "conv2d: stats buffer sized for %d-row blocks but the tile uses %d", a->stats_rows, wm);
     }
+    if (tile == 10) return conv_halo_dispatch(p, a->dtype, (hipStream_t)stream);
     if (a->dtype == ADVS_BF16) return conv_dispatch<BF16>(p, tile, (hipStream_t)stream);
     return conv_dispatch<float>(p, tile, (hipStream_t)stream);
 }

@@ -148,19 +148,20 @@ class Builder:
         Ho = (HL + 2 * pad - ksize) // stride + 1
         Wo = (WL + 2 * pad - ksize) // stride + 1
         y = out if out is not None else self.buf((B, Ho, Wo, cout))
-        stats, rows = None, 0
+        a = ConvArgs(ptr(x1), ptr(x2), ptr(w), ptr(bias), ptr(temb), ptr(residual), ptr(y),
+                     B, H, W, C1, C2, cout, ksize, stride, pad, 1 if upsample else 0,
+                     ACT[act], self.dt, temb_stride, tile, 0, 0,
+                     ptr(extra[0]) if extra else 0, ptr(extra[1]) if extra and extra[1] is not None else 0,
+                     extra[0].shape[3] if extra else 0, extra[1].shape[3] if extra and extra[1] is not None else 0)
+        stats = None
         if want_stats:
             # per-channel (sum, sumsq) per row block from the epilogue, for the GroupNorm that reads y
-            tile = tile or self.lib.advs_conv_pick_tile(B * Ho * Wo, cout)
-            rows = self.lib.advs_conv_tile_rows(tile)
+            a.tile = self.lib.advs_conv_resolve_tile(C.byref(a))
+            rows = self.lib.advs_conv_tile_rows(a.tile)
             if rows > 0 and (Ho * Wo) % rows == 0:
                 stats = self.buf((B * Ho * Wo // rows, cout, 2), torch.float32)
                 self.stats[y.data_ptr()] = (stats, Ho * Wo // rows)
-        a = ConvArgs(ptr(x1), ptr(x2), ptr(w), ptr(bias), ptr(temb), ptr(residual), ptr(y),
-                     B, H, W, C1, C2, cout, ksize, stride, pad, 1 if upsample else 0,
-                     ACT[act], self.dt, temb_stride, tile, ptr(stats), rows if stats is not None else 0,
-                     ptr(extra[0]) if extra else 0, ptr(extra[1]) if extra and extra[1] is not None else 0,
-                     extra[0].shape[3] if extra else 0, extra[1].shape[3] if extra and extra[1] is not None else 0)
+                a.stats, a.stats_rows = ptr(stats), rows
         self.plan.add(self.lib.advs_conv2d, C.byref(a), keep=(a, x1, x2, w, bias, temb, residual, y, stats, extra))
         return y
 

@@ -62,7 +62,8 @@ typedef struct advs_conv_args {
     int ksize, stride, pad, upsample;   /* ksize 1|3; upsample 0|1                          */
     int act, dtype;
     int temb_stride;                    /* floats between consecutive samples' temb rows    */
-    int tile;                           /* 0 = choose; 1: 128x128, 2|3: 256x128, 4: 256x256  */
+    int tile;                           /* 0 = choose; 1: 128x128, 2|3: 256x128, 4: 256x256,
+                                           10: 16x16-pixel halo tile (3x3 stride 1 only)       */
     float* stats;                       /* NULL, or [ceil(M/rows)][cout][2]: per row block (rows =
                                            advs_conv_tile_rows(tile), must divide ho*wo) and channel the
                                            (sum, sum of squares) of y as stored -> advs_groupnorm_stats */
@@ -74,7 +75,7 @@ typedef struct advs_conv_args {
 } advs_conv_args;
 int advs_conv2d(const advs_conv_args* a, void* stream);
 int advs_conv_set_tile(int tile);       /* tuning hook: non-zero overrides every call's tile  */
-int advs_conv_pick_tile(long long m, int cout);   /* the tile id tile = 0 resolves to for an m x cout output */
+int advs_conv_resolve_tile(const advs_conv_args* a);   /* the tile id advs_conv2d will use for this descriptor */
 int advs_conv_tile_rows(int tile);      /* row-block height (rows per stats entry) of a tile id */
 
 /* First conv: NCHW f32 image (cin <= 4) -> NHWC `dtype`, 3x3 pad 1 (diff_model.py:192;

@@ -38,14 +38,19 @@ CONV_CASES = [
     (2, 8, 8, 128, 64, 64, 1, 1, 0, 1, 0, 0, "relu"),      # concat 1x1 + relu
     (1, 32, 32, 64, 0, 256, 3, 1, 0, 0, 0, 0, "silu"),     # no bias, 2 N tiles, 8 M tiles
     (1, 14, 14, 256, 0, 64, 1, 2, 0, 1, 0, 0, None),       # 1x1 stride 2 (victim downsample path)
+    (2, 16, 16, 64, 128, 128, 3, 1, 0, 1, 1, 1, None),     # halo-eligible: concat, full epilogue
+    (1, 48, 32, 128, 0, 256, 3, 1, 0, 1, 0, 0, "silu"),    # halo-eligible: 3x2 pixel tiles, 2 channel tiles
+    (3, 16, 32, 64, 0, 64, 3, 1, 0, 0, 1, 0, None),        # halo-eligible: batch 3, N tail (64 < 128), 1 slab
 ]
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv2d(case, dt, tile):
     B, H, W, C1, C2, Cout, k, stride, ups, has_b, has_t, has_r, act = case
+    if tile == 10 and not (k == 3 and stride == 1 and not ups and H % 16 == 0 and W % 16 == 0):
+        pytest.skip("halo kernel: 3x3 stride 1, H and W multiples of 16")
     pad = 1 if k == 3 else 0
     x1 = rnd(B, C1, H, W, seed=1)
     x2 = rnd(B, C2, H, W, seed=2) if C2 else None
@@ -350,7 +355,7 @@ def test_groupnorm_chan_add(dt):
 
 # ------------------------------------------------------------------------------ GN statistics from the conv epilogue
 @pytest.mark.parametrize("dt", DTS)
-@pytest.mark.parametrize("tiles", [(1, 1), (4, 1), (1, 4), (3, 5)])
+@pytest.mark.parametrize("tiles", [(1, 1), (4, 1), (1, 4), (3, 5), (10, 1)])
 def test_groupnorm_with_epilogue_stats(dt, tiles):
     """conv(+stats) x2 -> GroupNorm(32) over their concat (groups of 12 straddle the sources) must equal
     the unfused path; statistics come from [row block][channel] partials written by the epilogues."""
