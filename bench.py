@@ -71,6 +71,26 @@ def conv_profile(eng, reps=2):
     return totals
 
 
+def conv_traffic_from_profiles():
+    """HBM bytes per conv launch from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in
+    separate runs, profiles/*_pmc_hbm_traffic.json; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
+    for wide coalesced reads on gfx950).  None when no PMC summary is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        d = json.load(f)
+    n = fetch = write = 0.0
+    for name, v in d.items():
+        if "conv_igemm_kernel" in name or "conv3x3_halo_kernel" in name:
+            n += v["launches"]
+            fetch += v["launches"] * v["FETCH_SIZE_KB_avg"] * 1024.0 * 2.0
+            write += v["launches"] * (v["WRITE_SIZE_KB_avg"] or 0.0) * 1024.0
+    return None if n == 0 else {"bytes_per_launch": (fetch + write) / n, "source": os.path.basename(files[-1]),
+                                "note": "PMC FETCH_SIZE x2 + WRITE_SIZE, averaged over the forward's conv launches"}
+
+
 def cpu_baseline(size, ddim_steps, budget_s=20.0):
     """The CPU oracle (oracle/lineage_b.py, torch-CPU fp32) on the host cores: B=1 forwards of the
     same network at the same resolution, extrapolated to a full ddim_steps-step image."""
@@ -178,8 +198,9 @@ def main():
         fwd_ms = sum(t[1] for t in tot.values())
         ach = c[2] / (c[1] * 1e-3) / 1e12
         peak = PEAK_MFMA_TFLOPS[args.dtype]
-        line["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel", "achieved": ach, "peak": peak,
-                            "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+        line["roofline"] = {"bound": "mfma", "kernel": "advs_conv2d (conv3x3_halo_kernel + conv_igemm_kernel)",
+                            "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                            "traffic": conv_traffic_from_profiles(),
                             "launches_per_forward": c[0], "avg_launch_ms": c[1] / c[0],
                             "algorithmic_gflop_per_launch": c[2] / c[0] / 1e9,
                             "forward_ms_by_kernel": {k: round(v[1], 3) for k, v in sorted(tot.items())},
