@@ -11,9 +11,11 @@
 //
 // Workgroup: 8 waves (4 along pixels x 2 along channels), each a 64x64 block of 32x32 MFMA tiles;
 // output tile 256 pixels x 128 channels.  LDS: A halo double-buffered per slab (2 x 42 KiB), B ring of
-// three 16 KiB stages with ONE barrier per tap.  The nine taps are unrolled so every counted
-// `s_waitcnt vmcnt(N)` is a literal: at the top of tap t the oldest outstanding group must be this
-// tap's weights, and the only younger traffic is next tap's weights plus at most two halo pieces.
+// FOUR 16 KiB stages with ONE barrier per tap.  The weights run two taps ahead, so the barrier that
+// opens tap t already publishes tap t+1's weights and the first fragments of tap t+1 are read during
+// the last MFMA group of tap t: no LDS latency is exposed after a barrier.  The nine taps are
+// unrolled so every counted `s_waitcnt vmcnt(N)` is a literal: at the top of tap t everything up to
+// W(t+1) must have landed, and the only younger traffic is W(t+2) plus at most two halo pieces.
 // Rows of 128 B are XOR-swizzled by (halo pixel >> 1) & 7 on the source address (see conv_igemm.hip).
 #include "conv_common.h"
 #include <type_traits>
@@ -26,12 +28,25 @@
 #define HB_STAGE (128 * SLAB)    // 16 KiB: 128 output channels x 128 B
 #define HNP 6                    // A pieces per wave per slab (8 waves x 6 >= 41)
 
+// MFMA row r of a 32-row tile <-> pixel (tile row g, column idx) of a 2 x 16 pixel strip.  ds_read_b128 serves
+// a wave in the fixed lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31}; giving each group 16 CONSECUTIVE
+// halo pixels makes (pixel & 1, (pixel >> 1) & 7) -- the 16-byte slot after the XOR swizzle -- distinct within
+// the group for every tap shift, i.e. the window reads are bank-conflict free.  The natural r -> (r >> 4, r & 15)
+// map is 2-way conflicted on every read (a group would straddle two halo rows).
+__device__ __forceinline__ void halo_row_map(int r, int& g, int& idx) {
+    const int blk = r >> 2;                          // 8 blocks of 4 rows: groups 0 1 1 0 1 0 0 1
+    g = (0x96 >> blk) & 1;
+    // position of this block among the blocks of its group, times 4
+    const int before = __builtin_popcount((g ? 0x96 : 0x69) & ((1 << blk) - 1));
+    idx = before * 4 + (r & 3);
+}
+
 template <typename T>
 __global__ void __launch_bounds__(512)
 conv3x3_halo_kernel(const ConvKP p) {
     constexpr int ESZ = Mma<T>::ESZ;
     constexpr int BKE = SLAB / ESZ;
-    extern __shared__ __attribute__((aligned(1024))) char smem[];   // [2][HA_STAGE] then [3][HB_STAGE]
+    extern __shared__ __attribute__((aligned(1024))) char smem[];   // [2][HA_STAGE] then [4][HB_STAGE]
     char* sA = smem;
     char* sB = smem + 2 * HA_STAGE;
 
@@ -94,7 +109,7 @@ conv3x3_halo_kernel(const ConvKP p) {
     };
     auto issue_B = [&](int unit, int t, int j) {     // weights of (slab unit, tap t): K offset t*Cin + unit*BKE
         const unsigned woff = (unsigned)(t * Cin + unit * BKE) * ESZ;
-        blds16(rsw, b_voff[j], woff, sB + (t % 3) * HB_STAGE + (wave * 2 + j) * 1024);
+        blds16(rsw, b_voff[j], woff, sB + ((unit * 9 + t) & 3) * HB_STAGE + (wave * 2 + j) * 1024);
     };
 
     // ---- fragment geometry: wave (wr, wc) owns tile rows 4wr..4wr+3 (x16 px) and channels wc*64..+63
@@ -102,7 +117,9 @@ conv3x3_halo_kernel(const ConvKP p) {
     int hidx0[2], b_off[2], b_sw[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        hidx0[i] = (4 * wr + 2 * i + (l31 >> 4)) * HWID + (l31 & 15);
+        int g, idx;
+        halo_row_map(l31, g, idx);
+        hidx0[i] = (4 * wr + 2 * i + g) * HWID + idx;
         const int rb = wc * 64 + i * 32 + l31;
         b_off[i] = rb * SLAB; b_sw[i] = (rb >> 1) & 7;
     }
@@ -115,12 +132,23 @@ conv3x3_halo_kernel(const ConvKP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // ---- prologue: halo of slab 0, weights of taps 0 and 1
+    // ---- prologue: halo of slab 0, weights of taps 0, 1 and 2
     set_a_voff(0);
 #pragma unroll
     for (int j = 0; j < HNP; ++j) issue_A(0, j);
     issue_B(0, 0, 0); issue_B(0, 0, 1);
     issue_B(0, 1, 0); issue_B(0, 1, 1);
+    issue_B(0, 2, 0); issue_B(0, 2, 1);
+
+    u32x4 af[2][2], bf[2][2];                        // [k-step parity][tile]; slot 0 is carried across taps
+    auto load_frags = [&](int slot, const char* la, const char* lb, int r, int s, int ks) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int hidx = hidx0[i] + r * HWID + s;
+            af[slot][i] = *(const u32x4*)(la + hidx * SLAB + (((2 * ks + lh) ^ ((hidx >> 1) & 7)) << 4));
+            bf[slot][i] = *(const u32x4*)(lb + b_off[i] + (((2 * ks + lh) ^ b_sw[i]) << 4));
+        }
+    };
 
     for (int unit = 0; unit < nunits; ++unit) {
         const bool hn = unit + 1 < nunits;           // a next slab exists: its halo is prefetched during this one
@@ -128,47 +156,33 @@ conv3x3_halo_kernel(const ConvKP p) {
         const char* la = sA + (unit & 1) * HA_STAGE;
         auto tap = [&](auto tc) {
             constexpr int t = decltype(tc)::value;
-            // Outstanding, oldest first: W(t) [+halo piece t-2], W(t+1) [+halo piece t-1].  Wait for W(t).
+            const int it = unit * 9 + t;
+            // Outstanding, oldest first: W(t+1) [+halo piece t-2], W(t+2) [+halo piece t-1].  Wait for W(t+1).
             constexpr int nA = ((t - 2 >= 0 && t - 2 < HNP) ? 1 : 0) + ((t - 1 >= 0 && t - 1 < HNP) ? 1 : 0);
-            if (t < 8) {
-                if (hn) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + nA) : "memory");
-                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            } else {
-                if (hn) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
+            if (hn) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + nA) : "memory");
+            else if (t < 7) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            // (unit, t+2) wraps into the next slab for t = 7, 8
-            const bool wb = t < 7 || hn;
-            const int u2 = t < 7 ? unit : unit + 1, t2 = t < 7 ? t + 2 : t - 7;
+            // W(it+3) wraps into the next slab for t = 6, 7, 8
+            const bool wb = t < 6 || hn;
+            const int u3 = t < 6 ? unit : unit + 1, t3 = t < 6 ? t + 3 : t - 6;
             const int r = t / 3, s = t % 3;
-            const char* lb = sB + (t % 3) * HB_STAGE;
-            int a_row[2], a_sw[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int hidx = hidx0[i] + r * HWID + s;
-                a_row[i] = hidx * SLAB; a_sw[i] = (hidx >> 1) & 7;
-            }
-            u32x4 af[2][2], bf[2][2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                af[0][i] = *(const u32x4*)(la + a_row[i] + (((0 + lh) ^ a_sw[i]) << 4));
-                bf[0][i] = *(const u32x4*)(lb + b_off[i] + (((0 + lh) ^ b_sw[i]) << 4));
-            }
+            const char* lb = sB + (it & 3) * HB_STAGE;
+            if (it == 0) load_frags(0, la, lb, r, s, 0);              // nothing was carried into the very first tap
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int cur = ks & 1, nxt = cur ^ 1;
                 if (ks < 3) {
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        af[nxt][i] = *(const u32x4*)(la + a_row[i] + (((2 * (ks + 1) + lh) ^ a_sw[i]) << 4));
-                        bf[nxt][i] = *(const u32x4*)(lb + b_off[i] + (((2 * (ks + 1) + lh) ^ b_sw[i]) << 4));
-                    }
+                    load_frags(nxt, la, lb, r, s, ks + 1);
+                } else if (t < 8) {                                   // first fragments of the next tap, same slab
+                    load_frags(nxt, la, sB + ((it + 1) & 3) * HB_STAGE, (t + 1) / 3, (t + 1) % 3, 0);
+                } else if (hn) {                                      // ... or tap 0 of the next slab's halo
+                    load_frags(nxt, sA + ((unit + 1) & 1) * HA_STAGE, sB + ((it + 1) & 3) * HB_STAGE, 0, 0, 0);
                 }
                 // this tap's share of the DMA issue, spread between the MFMA groups (weights first)
-                if (ks == 0 && wb) issue_B(u2, t2, 0);
-                if (ks == 1 && wb) issue_B(u2, t2, 1);
+                if (ks == 0 && wb) issue_B(u3, t3, 0);
+                if (ks == 1 && wb) issue_B(u3, t3, 1);
                 if (ks == 2 && hn && t < HNP) issue_A(unit + 1, t);
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -186,7 +200,11 @@ conv3x3_halo_kernel(const ConvKP p) {
     __builtin_amdgcn_s_barrier();                    // every wave is done reading before the patches reuse LDS
 
     conv_epilogue<T, 64, 2, 2>(p, acc, (float*)smem + wave * (32 * 64), lane, n0 + wc * 64,
-                               [&](int lr) { return (b * p.H + y0 + 4 * wr + (lr >> 4)) * p.W + x0 + (lr & 15); },
+                               [&](int lr) {
+                                   int g, idx;
+                                   halo_row_map(lr & 31, g, idx);
+                                   return (b * p.H + y0 + 4 * wr + 2 * (lr >> 5) + g) * p.W + x0 + idx;
+                               },
                                p.temb ? b : -1, tl * 4 + wr);
 }
 
@@ -199,7 +217,7 @@ bool conv_halo_eligible(const ConvKP& p) {
 
 template <typename T>
 static int halo_launch(ConvKP& p, hipStream_t st) {
-    constexpr int lds = 2 * HA_STAGE + 3 * HB_STAGE;
+    constexpr int lds = 2 * HA_STAGE + 4 * HB_STAGE;
     static bool attr_set = false;
     if (!attr_set) {
         ADVS_HIP(hipFuncSetAttribute((const void*)conv3x3_halo_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
