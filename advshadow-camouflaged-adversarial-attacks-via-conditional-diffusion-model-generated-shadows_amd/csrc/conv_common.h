@@ -87,20 +87,18 @@ __device__ __forceinline__ void conv_epilogue(const ConvKP& p, f32x16 (&acc)[TM]
 #pragma unroll
         for (int e = 0; e < VEC; ++e) bias[e] += tp[e];
     }
-    // residual vectors are requested up front so their latency overlaps the LDS transposes below
     constexpr int NIT = 32 / RPI;
-    u32x4 rraw[TM][NIT];
-    if (res) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i) {
+        // this strip's residual vectors are requested first so their latency overlaps the LDS transpose
+        u32x4 rraw[NIT];
+        if (res) {
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int m = row_to_m(i * 32 + it * RPI + prow);
-                rraw[i][it] = (m >= 0 && n_ok) ? *(const u32x4*)(res + (size_t)m * p.Cout + n) : u32x4{0, 0, 0, 0};
+                rraw[it] = (m >= 0 && n_ok) ? *(const u32x4*)(res + (size_t)m * p.Cout + n) : u32x4{0, 0, 0, 0};
             }
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -130,7 +128,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKP& p, f32x16 (&acc)[TM]
                 }
                 if (res) {
                     float rv[VEC];
-                    unpack16<T>(rraw[i][it], rv);
+                    unpack16<T>(rraw[it], rv);
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) v[e] += rv[e];
                 }
