@@ -169,7 +169,41 @@ def gen_samplers():
     save("lineage_a_samplers.npz", **arrs)
 
 
-GROUPS = {"lineage_b": gen_lineage_b, "lineage_a": gen_lineage_a, "samplers": gen_samplers}
+# --------------------------------------------------------------------------- CSPDarkUnet (second --network)
+def gen_cspdark():
+    from model.networks.cspdarkunet import CSPDarkUnet
+    from model.samples.ddim import DDIMDiffusion
+    import model.samples.ddim as ddim_mod
+    ddim_mod.tqdm = lambda it, **k: it
+
+    def run(tag, seed, act, with_sample):
+        torch.manual_seed(seed)
+        net = CSPDarkUnet(num_classes=37, device="cpu", image_size=64, act=act).eval()
+        keys, dg = digest(net.state_dict())
+        g = torch.Generator().manual_seed(3000 + seed)
+        x = torch.randn(2, 3, 64, 64, generator=g)
+        t = torch.tensor([47, 873])
+        y = torch.tensor([9, 36])
+        arrs = dict(sd_keys=keys, sd_digest=dg, x=x.numpy(), t=t.numpy(), y=y.numpy())
+        with torch.no_grad():
+            arrs["eps_cond"] = net(x, t, y).numpy()
+            arrs["eps_uncond"] = net(x, t).numpy()
+        if with_sample:
+            diff = DDIMDiffusion(sample_steps=10, img_size=64, device="cpu")
+            labels = torch.tensor([12, 2])
+            torch.manual_seed(5151)
+            arrs["sample_xT"] = torch.randn((2, 3, 64, 64)).numpy()
+            arrs["sample_labels"] = labels.numpy()
+            torch.manual_seed(5151)
+            arrs["sample_cfg3"] = diff.sample(net, 2, labels=labels, cfg_scale=3).numpy()
+            net.eval()
+        save(f"cspdark_{tag}.npz", **arrs)
+
+    run("silu", 3, "silu", True)
+    run("lrelu", 4, "lrelu", False)
+
+
+GROUPS = {"lineage_b": gen_lineage_b, "lineage_a": gen_lineage_a, "samplers": gen_samplers, "cspdark": gen_cspdark}
 
 if __name__ == "__main__":
     for g in (sys.argv[1:] or list(GROUPS)):
