@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libadvshadow_hip.so")
 
 F32, BF16 = 0, 1
 ACT = {"none": 0, None: 0, "relu": 1, "silu": 2, "gelu": 3, "relu6": 4, "lrelu": 5, "lrelu001": 6}
+GN_RESIDUAL_AFTER_ACT = 0x100      # include/advshadow.h
 
 vp, i32, f32, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
@@ -20,7 +21,8 @@ class ConvArgs(C.Structure):
     _fields_ = [("x1", vp), ("x2", vp), ("w", vp), ("bias", vp), ("temb", vp), ("residual", vp), ("y", vp),
                 ("b", i32), ("h", i32), ("w_", i32), ("c1", i32), ("c2", i32), ("cout", i32),
                 ("ksize", i32), ("stride", i32), ("pad", i32), ("upsample", i32),
-                ("act", i32), ("dtype", i32), ("temb_stride", i32), ("tile", i32), ("stats", vp), ("stats_rows", i32), ("e1", vp), ("e2", vp), ("ce1", i32), ("ce2", i32)]
+                ("act", i32), ("dtype", i32), ("temb_stride", i32), ("tile", i32), ("stats", vp), ("stats_rows", i32), ("e1", vp), ("e2", vp), ("ce1", i32), ("ce2", i32),
+                ("ld1", i32), ("ld2", i32)]
 
 
 # name -> argtypes (restype is int unless listed in _RESTYPES)
@@ -40,6 +42,7 @@ SIGNATURES = {
     "advs_groupnorm": [vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "advs_maxpool2": [vp, vp, i32, i32, i32, i32, i32, vp],
     "advs_concat_upsample2x": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "advs_concat_nearest2x": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "advs_layernorm": [vp, vp, vp, vp, C.c_longlong, i32, f32, i32, vp],
     "advs_attention_masked": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "advs_patchify": [vp, vp, i32, i32, i32, i32, i32, i32, vp],

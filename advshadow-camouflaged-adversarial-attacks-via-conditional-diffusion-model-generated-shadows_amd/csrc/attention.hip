@@ -44,7 +44,8 @@ attn_kernel(const AttnP p) {
     const int q0 = blockIdx.x * 128 + wave * 32;
     const bool active = q0 < p.N;
     const int d = p.d;
-    const int dsteps = d * ESZ / 32;              // 32-byte steps actually used
+    const int dbytes = d * ESZ;                   // a multiple of 16; a trailing half step is zero-filled
+    const int dsteps = (dbytes + 31) / 32;        // 32-byte steps actually used
     const size_t rowb = (size_t)p.ld * ESZ;
     const char* base = p.qkv + (size_t)b * p.N * rowb;
     const char* qp = base + (size_t)(p.q_off + hd * p.head_stride) * ESZ;
@@ -55,7 +56,7 @@ attn_kernel(const AttnP p) {
     u32x4 qf[QSTEPS];
 #pragma unroll
     for (int s = 0; s < QSTEPS; ++s) {
-        if (active && s < dsteps) qf[s] = *(const u32x4*)(qp + (size_t)(q0 + l31) * rowb + s * 32 + lh * 16);
+        if (q0 + l31 < p.N && s * 32 + lh * 16 < dbytes) qf[s] = *(const u32x4*)(qp + (size_t)(q0 + l31) * rowb + s * 32 + lh * 16);
         else qf[s] = u32x4{0, 0, 0, 0};
     }
 
@@ -66,16 +67,19 @@ attn_kernel(const AttnP p) {
         for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
-    const int cpr = d * ESZ / 16;                 // 16-byte chunks per K/V row
-    const int nvec = KT * cpr;
+    const int cpr = dbytes / 16;                  // 16-byte chunks per K/V row
+    const int cprp = dsteps * 2;                  // ... of the K tile incl. the zero half step
+    const int nvec = KT * cprp;
 
     for (int k0 = 0; k0 < p.n_valid; k0 += KT) {
         __syncthreads();                          // previous tile fully consumed
         for (int v = tid; v < nvec; v += AT_THREADS) {
-            const int key = v / cpr, ch = v - key * cpr;
+            const int key = v / cprp, ch = v - key * cprp;
             const size_t g = (size_t)(k0 + key) * rowb + ch * 16;
-            const u32x4 kv = *(const u32x4*)(kp + g);
-            const u32x4 vv = *(const u32x4*)(vp + g);
+            if (ch >= cpr) { *(u32x4*)(sK + key * KS + ch * 16) = u32x4{0, 0, 0, 0}; continue; }
+            const bool in = k0 + key < p.N;           // the last tile of a short sequence (N = 16 at 4x4) is zero-filled
+            const u32x4 kv = in ? *(const u32x4*)(kp + g) : u32x4{0, 0, 0, 0};
+            const u32x4 vv = in ? *(const u32x4*)(vp + g) : u32x4{0, 0, 0, 0};
             *(u32x4*)(sK + key * KS + ch * 16) = kv;
             if (ESZ == 2) {
 #pragma unroll
@@ -173,7 +177,7 @@ attn_kernel(const AttnP p) {
             }
         }
     }
-    if (!active) return;
+    if (!active || q0 + l31 >= p.N) return;
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
     T* orow = (T*)p.out + ((size_t)b * p.N + q0 + l31) * (size_t)(p.heads * d) + hd * d;
@@ -214,10 +218,9 @@ static int attn_launch(const AttnP& p, hipStream_t st) {
 static int attention_impl(const void* qkv, void* out, int b, int n, int n_valid, int heads, int d, int ld,
                           int q_off, int k_off, int v_off, int head_stride, int dtype, void* stream) {
     ADVS_REQUIRE(qkv && out && b > 0 && n > 0 && heads > 0 && d > 0, "attention: bad args");
-    ADVS_REQUIRE(n % KT == 0, "attention: n=%d must be a multiple of %d", n, KT);
     ADVS_REQUIRE(n_valid > 0 && n_valid <= n, "attention: n_valid=%d out of range", n_valid);
-    ADVS_REQUIRE(d % 16 == 0 && d <= 128, "attention: d=%d must be a multiple of 16 and <= 128", d);
     const int vec = dtype == ADVS_BF16 ? 8 : 4;
+    ADVS_REQUIRE(d % vec == 0 && d <= 128, "attention: d=%d must be a multiple of %d and <= 128", d, vec);
     ADVS_REQUIRE(ld % vec == 0 && q_off % vec == 0 && k_off % vec == 0 && v_off % vec == 0 && head_stride % vec == 0,
                  "attention: offsets must keep 16-byte alignment");
     AttnP p;

@@ -24,6 +24,7 @@ struct ConvKP {
     float* stats;                // [ceil(M/WM)][Cout][2] per-channel (sum, sum of squares) of y, or null
     unsigned x1_bytes, x2_bytes, w_bytes;
     int B, H, W, C1, C2, Cout;
+    int LD1, LD2;                // pixel strides of x1 / x2 in elements (<= C1 / C2, see advs_conv_args.ld1)
     int R, stride, pad, ups;
     int Ho, Wo, M, K;            // K in elements
     int act, temb_stride;

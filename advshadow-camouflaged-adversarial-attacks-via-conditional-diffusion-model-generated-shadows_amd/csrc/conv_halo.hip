@@ -98,7 +98,7 @@ conv3x3_halo_kernel(const ConvKP p) {
     const int total_it = nunits * 9;
 
     auto set_a_voff = [&](int unit) {                // byte offsets of the halo pixels in `unit`'s source
-        const unsigned cs = (unsigned)(unit < ncs1 ? p.C1 : p.C2) * ESZ;
+        const unsigned cs = (unsigned)(unit < ncs1 ? p.LD1 : p.LD2) * ESZ;
 #pragma unroll
         for (int j = 0; j < HNP; ++j) a_voff[j] = apix[j] >= 0 ? (unsigned)apix[j] * cs + acsw[j] : OOB_OFFSET;
     };

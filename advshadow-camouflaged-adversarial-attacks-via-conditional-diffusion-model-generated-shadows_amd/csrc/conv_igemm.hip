@@ -108,7 +108,7 @@ conv_igemm_kernel(const ConvKP p) {
             st_sel = first ? 0 : 1;
             if (c0 == 0 || c0 == p.C1) {
                 // new (tap, source) segment: per-row byte offset of the source pixel, or out of range
-                const unsigned cs = (unsigned)(first ? p.C1 : p.C2) * ESZ;
+                const unsigned cs = (unsigned)(first ? p.LD1 : p.LD2) * ESZ;
 #pragma unroll
                 for (int j = 0; j < AR; ++j) {
                     const int iy = a_iy[j] + kr, ix = a_ix[j] + ks;
@@ -384,6 +384,9 @@ extern "C" int advs_conv2d(const advs_conv_args* a, void* stream) {
     p.bias = a->bias; p.temb = a->temb; p.res = (const char*)a->residual; p.y = (char*)a->y;
     p.stats = a->stats;
     p.B = a->b; p.H = a->h; p.W = a->w_; p.C1 = a->c1; p.C2 = a->c2; p.Cout = a->cout;
+    p.LD1 = a->ld1 > 0 ? a->ld1 : a->c1; p.LD2 = a->ld2 > 0 ? a->ld2 : a->c2;
+    ADVS_REQUIRE(p.LD1 <= a->c1 && p.LD2 <= a->c2 && (p.LD1 * esz) % 16 == 0 && (p.LD2 * esz) % 16 == 0 && a->ld1 >= 0 && a->ld2 >= 0,
+                 "conv2d: pixel strides (%d,%d) must be 16-byte multiples and <= the channel counts (%d,%d)", a->ld1, a->ld2, a->c1, a->c2);
     p.R = a->ksize; p.stride = a->stride; p.pad = a->pad; p.ups = a->upsample ? 1 : 0;
     const int HL = a->h << p.ups, WL = a->w_ << p.ups;
     p.Ho = (HL + 2 * a->pad - a->ksize) / a->stride + 1;
@@ -396,8 +399,8 @@ extern "C" int advs_conv2d(const advs_conv_args* a, void* stream) {
     const unsigned long long e1b = (unsigned long long)M * a->ce1 * esz, e2b = (unsigned long long)M * a->ce2 * esz;
     ADVS_REQUIRE(e1b < 0xF0000000ull && e2b < 0xF0000000ull, "conv2d: extra operand exceeds the 32-bit buffer offsets");
     p.e1_bytes = (unsigned)(a->e1 ? e1b : 16); p.e2_bytes = (unsigned)(a->e2 ? e2b : 16);
-    const unsigned long long x1b = (unsigned long long)a->b * a->h * a->w_ * a->c1 * esz;
-    const unsigned long long x2b = (unsigned long long)a->b * a->h * a->w_ * a->c2 * esz;
+    const unsigned long long x1b = (unsigned long long)a->b * a->h * a->w_ * p.LD1 * esz;
+    const unsigned long long x2b = (unsigned long long)a->b * a->h * a->w_ * p.LD2 * esz;
     const unsigned long long wb = (unsigned long long)a->cout * p.K * esz;
     ADVS_REQUIRE(x1b < 0xF0000000ull && x2b < 0xF0000000ull && wb < 0xF0000000ull,
                  "conv2d: a source of %llu bytes exceeds the 32-bit buffer offsets (split the batch)", x1b > x2b ? x1b : x2b);

@@ -136,6 +136,8 @@ gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ x2, int C1, const
                           : (const u32x4*)x2 + (size_t)b * HW * (vpp - v1) + (cv - v1);
     const u32x4* rb = res ? (const u32x4*)res + sample + cv : nullptr;
     u32x4* yb = (u32x4*)y + sample + cv;
+    const bool res_after = (act & ADVS_GN_RESIDUAL_AFTER_ACT) != 0;     // act(norm(x)) + residual (module.py:45-46)
+    act &= ~ADVS_GN_RESIDUAL_AFTER_ACT;
     auto one = [&](const u32x4& raw, const u32x4& rraw) -> u32x4 {
         float f[VEC], r[VEC];
         unpack16<T>(raw, f);
@@ -143,8 +145,10 @@ gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ x2, int C1, const
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             float v = fmaf(f[j], ca[j], cb[j]);
-            if (rb) v += r[j];
-            f[j] = apply_act_t<T>(v, act) + cc[j];
+            if (rb && !res_after) v += r[j];
+            v = apply_act_t<T>(v, act) + cc[j];
+            if (rb && res_after) v += r[j];
+            f[j] = v;
         }
         return pack16<T>(f);
     };

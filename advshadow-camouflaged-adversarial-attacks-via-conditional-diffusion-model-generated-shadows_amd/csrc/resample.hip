@@ -47,7 +47,8 @@ extern "C" int advs_maxpool2(const void* x, void* y, int b, int h, int w, int c,
 
 // ------------------------------------------- cat([skip, Upsample(x2, bilinear, align_corners)(x)])
 // (block.py:66,86-87).  Source index = dst * (in-1)/(out-1), weights as torch's CPU kernel forms them.
-template <typename T>
+// NEAREST: cat([skip, Upsample(x2, nearest)(x)]) of CSPDarkUpBlock (block.py:116,127-128): source = dst >> 1.
+template <typename T, bool NEAREST>
 __global__ void concat_up_kernel(const T* __restrict__ skip, const T* __restrict__ x, T* __restrict__ y,
                                  int B, int h, int w, int C1, int C2) {
     constexpr int VEC = Elt<T>::VEC;
@@ -68,6 +69,10 @@ __global__ void concat_up_kernel(const T* __restrict__ skip, const T* __restrict
             yv[i] = sv[(((size_t)b * H + oy) * W + ox) * v1 + cv];
             continue;
         }
+        if (NEAREST) {
+            yv[i] = xv[(((size_t)b * h + (oy >> 1)) * w + (ox >> 1)) * v2 + (cv - v1)];
+            continue;
+        }
         const float fy = sh * oy, fx = sw * ox;
         const int y0 = (int)fy, x0 = (int)fx;
         const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
@@ -84,19 +89,29 @@ __global__ void concat_up_kernel(const T* __restrict__ skip, const T* __restrict
     }
 }
 
-extern "C" int advs_concat_upsample2x(const void* skip, const void* x, void* y, int b, int h, int w, int c1, int c2,
-                                      int dtype, void* stream) {
-    ADVS_REQUIRE(skip && x && y && b > 0 && h > 0 && w > 0, "concat_upsample2x: bad args");
+template <bool NEAREST>
+static int concat_up_launch(const char* name, const void* skip, const void* x, void* y, int b, int h, int w, int c1, int c2,
+                            int dtype, void* stream) {
+    ADVS_REQUIRE(skip && x && y && b > 0 && h > 0 && w > 0, "%s: bad args", name);
     const int vec = dtype == ADVS_BF16 ? 8 : 4;
-    ADVS_REQUIRE(c1 % vec == 0 && c2 % vec == 0 && c2 > 0, "concat_upsample2x: channels must be multiples of %d", vec);
+    ADVS_REQUIRE(c1 % vec == 0 && c2 % vec == 0 && c2 > 0, "%s: channels must be multiples of %d", name, vec);
     const size_t total = (size_t)b * 4 * h * w * ((c1 + c2) / vec);
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     if (dtype == ADVS_BF16)
-        concat_up_kernel<BF16><<<grid, 256, 0, (hipStream_t)stream>>>((const BF16*)skip, (const BF16*)x, (BF16*)y, b, h, w, c1, c2);
+        concat_up_kernel<BF16, NEAREST><<<grid, 256, 0, (hipStream_t)stream>>>((const BF16*)skip, (const BF16*)x, (BF16*)y, b, h, w, c1, c2);
     else
-        concat_up_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>((const float*)skip, (const float*)x, (float*)y, b, h, w, c1, c2);
-    ADVS_CHECK_LAUNCH("concat_upsample2x");
+        concat_up_kernel<float, NEAREST><<<grid, 256, 0, (hipStream_t)stream>>>((const float*)skip, (const float*)x, (float*)y, b, h, w, c1, c2);
+    ADVS_CHECK_LAUNCH(name);
     return ADVS_OK;
+}
+
+extern "C" int advs_concat_upsample2x(const void* skip, const void* x, void* y, int b, int h, int w, int c1, int c2,
+                                      int dtype, void* stream) {
+    return concat_up_launch<false>("concat_upsample2x", skip, x, y, b, h, w, c1, c2, dtype, stream);
+}
+extern "C" int advs_concat_nearest2x(const void* skip, const void* x, void* y, int b, int h, int w, int c1, int c2,
+                                     int dtype, void* stream) {
+    return concat_up_launch<true>("concat_nearest2x", skip, x, y, b, h, w, c1, c2, dtype, stream);
 }
 
 // ---------------------------------------------------------------- LayerNorm over the channel axis

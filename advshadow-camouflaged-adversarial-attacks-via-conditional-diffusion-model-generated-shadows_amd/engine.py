@@ -11,7 +11,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import ACT, BF16, F32, ConvArgs, check
+from ._lib import ACT, BF16, F32, GN_RESIDUAL_AFTER_ACT, ConvArgs, check
 
 TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16}
 ESZ = {F32: 4, BF16: 2}
@@ -142,8 +142,12 @@ class Builder:
              ksize=3, stride=1, pad=1, upsample=False, act=None, out=None, tile=0, want_stats=False, extra=None):
         """extra = (e1, e2_or_None): NHWC tensors at the OUTPUT resolution whose 1x1 conv is summed in;
         ``w`` then holds [taps * (C1 + C2) | E1 + E2] per output channel."""
-        B, H, W, C1 = x1.shape
-        C2 = 0 if x2 is None else x2.shape[3]
+        B, H, W, L1 = x1.shape
+        L2 = 0 if x2 is None else x2.shape[3]
+        # a source whose channel count is not a whole number of 128-byte slabs is read with pixel stride L and
+        # K extent C (rounded up); pack_conv_weight zero-fills the weights of the surplus channels
+        slab = SLAB_ELEMS[self.dt]
+        C1, C2 = -(-L1 // slab) * slab, -(-L2 // slab) * slab
         HL, WL = (H * 2, W * 2) if upsample else (H, W)
         Ho = (HL + 2 * pad - ksize) // stride + 1
         Wo = (WL + 2 * pad - ksize) // stride + 1
@@ -152,7 +156,12 @@ class Builder:
                      B, H, W, C1, C2, cout, ksize, stride, pad, 1 if upsample else 0,
                      ACT[act], self.dt, temb_stride, tile, 0, 0,
                      ptr(extra[0]) if extra else 0, ptr(extra[1]) if extra and extra[1] is not None else 0,
-                     extra[0].shape[3] if extra else 0, extra[1].shape[3] if extra and extra[1] is not None else 0)
+                     extra[0].shape[3] if extra else 0, extra[1].shape[3] if extra and extra[1] is not None else 0,
+                     L1 if L1 != C1 else 0, L2 if L2 != C2 else 0)
+        kw = ksize * ksize * (C1 + C2) + a.ce1 + a.ce2
+        if w.numel() != cout * kw:
+            raise ValueError(f"conv: packed weight has {w.numel()} elements, expected {cout} x {kw} "
+                             f"(sources {L1}+{L2} channels, slab {slab})")
         stats = None
         if want_stats:
             # per-channel (sum, sumsq) per row block from the epilogue, for the GroupNorm that reads y
@@ -178,8 +187,10 @@ class Builder:
                       keep=(x, w, bias, out_nchw))
         return out_nchw
 
-    def groupnorm(self, x, gamma, beta, groups, act=None, x2=None, residual=None, chan_add=None, chan_add_stride=0):
+    def groupnorm(self, x, gamma, beta, groups, act=None, x2=None, residual=None, chan_add=None, chan_add_stride=0,
+                  residual_after_act=False):
         B, H, W, C1 = x.shape
+        actc = ACT[act] | (GN_RESIDUAL_AFTER_ACT if residual_after_act else 0)
         C2 = 0 if x2 is None else x2.shape[3]
         y = self.buf((B, H, W, C1 + C2))
         s1 = self.stats.get(x.data_ptr())
@@ -188,10 +199,10 @@ class Builder:
             self.plan.add(self.lib.advs_groupnorm_stats, ptr(x), ptr(x2), ptr(s1[0]), s1[1],
                           ptr(s2[0]) if s2 else 0, s2[1] if s2 else 0, ptr(gamma), ptr(beta), ptr(residual),
                           ptr(chan_add), chan_add_stride, ptr(y), ptr(self.gn_scratch), B, H * W, C1, C2, groups,
-                          ACT[act], self.dt, keep=(x, x2, s1, s2, gamma, beta, residual, chan_add, y))
+                          actc, self.dt, keep=(x, x2, s1, s2, gamma, beta, residual, chan_add, y))
             return y
         self.plan.add(self.lib.advs_groupnorm, ptr(x), ptr(x2), ptr(gamma), ptr(beta), ptr(residual), ptr(chan_add),
-                      chan_add_stride, ptr(y), ptr(self.gn_scratch), B, H * W, C1, C2, groups, ACT[act], self.dt,
+                      chan_add_stride, ptr(y), ptr(self.gn_scratch), B, H * W, C1, C2, groups, actc, self.dt,
                       keep=(x, x2, gamma, beta, residual, chan_add, y))
         return y
 
@@ -206,6 +217,14 @@ class Builder:
         C1 = skip.shape[3]
         y = self.buf((B, 2 * h, 2 * w, C1 + C2))
         self.plan.add(self.lib.advs_concat_upsample2x, ptr(skip), ptr(x), ptr(y), B, h, w, C1, C2, self.dt,
+                      keep=(skip, x, y))
+        return y
+
+    def concat_nearest2x(self, skip, x):
+        B, h, w, C2 = x.shape
+        C1 = skip.shape[3]
+        y = self.buf((B, 2 * h, 2 * w, C1 + C2))
+        self.plan.add(self.lib.advs_concat_nearest2x, ptr(skip), ptr(x), ptr(y), B, h, w, C1, C2, self.dt,
                       keep=(skip, x, y))
         return y
 
@@ -239,10 +258,25 @@ class Builder:
         return y
 
 
-def pack_conv_weight(w, dt, stream=None):
-    """torch OIHW f32 (device) -> [O][R][S][I] in the compute dtype, on the current stream."""
+def pack_conv_weight(w, dt, stream=None, sources=None):
+    """torch OIHW f32 (device) -> [O][R][S][I] in the compute dtype, on the current stream.  ``sources`` =
+    channel counts of the concatenated inputs (default: one source); each is zero-padded to a whole number of
+    128-byte slabs, matching how Builder.conv presents such a source to the kernel."""
     lib = _lib.load()
-    w = w.detach().contiguous().float()
+    w = w.detach().float()
+    slab = SLAB_ELEMS[dt]
+    sources = tuple(sources) if sources else (w.shape[1],)
+    if sum(sources) != w.shape[1]:
+        raise ValueError(f"pack_conv_weight: sources {sources} do not add up to {w.shape[1]} input channels")
+    if any(c % slab for c in sources):
+        parts, o = [], 0
+        for c in sources:
+            parts.append(w[:, o:o + c])
+            if c % slab:
+                parts.append(torch.zeros((w.shape[0], slab - c % slab) + tuple(w.shape[2:]), dtype=w.dtype, device=w.device))
+            o += c
+        w = torch.cat(parts, dim=1)
+    w = w.contiguous()
     O, I, R, S = w.shape
     out = torch.empty((O, R, S, I), dtype=TORCH_DT[dt], device=w.device)
     s = (stream or torch.cuda.current_stream(w.device)).cuda_stream

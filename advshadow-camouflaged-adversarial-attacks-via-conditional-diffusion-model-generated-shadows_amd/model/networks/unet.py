@@ -157,7 +157,8 @@ class UNet(nn.Module):
 class _UNetEngine:
     """Frozen plans of one UNet forward for (batch, dtype): 'cond', 'uncond' and 'cfg' (both)."""
 
-    def __init__(self, model, W, batch, dt):
+    def __init__(self, model, W, batch, dt, emit=None):
+        self.emit = emit or emit_unet_forward                  # appends one forward to a Builder's plan
         dev = next(model.parameters()).device
         self.model, self.W, self.B, self.dt, self.dev = model, W, batch, dt, dev
         self.stream = torch.cuda.Stream(device=dev)
@@ -177,9 +178,9 @@ class _UNetEngine:
                 if mode in ("cond", "cfg"):
                     if self.model.num_classes is None:
                         raise ValueError("labels were given but the network has no label_emb (num_classes=None)")
-                    emit_unet_forward(bld, self.model, self.W, self.x, self.t, self.labels, self.eps_c)
+                    self.emit(bld, self.model, self.W, self.x, self.t, self.labels, self.eps_c)
                 if mode in ("uncond", "cfg"):
-                    emit_unet_forward(bld, self.model, self.W, self.x, self.t, None, self.eps_u)
+                    self.emit(bld, self.model, self.W, self.x, self.t, None, self.eps_u)
                 torch.cuda.synchronize(self.dev)
             pl = bld.plan
             self.plans[mode] = pl

@@ -3,6 +3,7 @@ import logging
 
 import torch
 
+from ..model.networks.cspdarkunet import CSPDarkUnet
 from ..model.networks.unet import UNet
 from ..model.samples.ddim import DDIMDiffusion
 from ..model.samples.ddpm import DDPMDiffusion
@@ -20,9 +21,9 @@ def device_initializer(device_id=0, is_train=False):
 
 
 def network_initializer(network, device):
-    """utils/initializer.py:81-96 ('cspdarkunet' is not built yet; unknown names fall back to unet)."""
+    """utils/initializer.py:81-96 (unknown names fall back to unet, as in the reference)."""
     if network == "cspdarkunet":
-        raise NotImplementedError("CSPDarkUnet is listed as a next row (SURVEY 8f rank 2) and is not built yet")
+        return CSPDarkUnet
     if network != "unet":
         logger.warning("[%s]: Setting network error, we has been automatically set to unet.", device)
     return UNet

@@ -26,6 +26,10 @@ enum { ADVS_OK = 0, ADVS_ERR_ARG = -1, ADVS_ERR_HIP = -2, ADVS_ERR_STATE = -3 };
 enum { ADVS_F32 = 0, ADVS_BF16 = 1 };
 enum { ADVS_ACT_NONE = 0, ADVS_ACT_RELU = 1, ADVS_ACT_SILU = 2, ADVS_ACT_GELU = 3,
        ADVS_ACT_RELU6 = 4, ADVS_ACT_LRELU01 = 5, ADVS_ACT_LRELU001 = 6 };
+/* OR-ed into advs_groupnorm*'s `act`: y = act(norm(x)) + chan_add + residual instead of
+ * act(norm(x) + residual) + chan_add -- Bottleneck's `y = conv2(conv1(x)); y = y + x`
+ * (model/modules/module.py:42-47) where conv2 is Conv -> GroupNorm -> act (conv.py:96-97).   */
+#define ADVS_GN_RESIDUAL_AFTER_ACT 0x100
 
 /* ---- library ---------------------------------------------------------------------- */
 int advs_init(void);                    /* allocate the zero page on the current device   */
@@ -72,6 +76,11 @@ typedef struct advs_conv_args {
                                            y = conv(x) + conv1x1(cat(e1,e2)); w rows are then
                                            [ksize*ksize*(c1+c2) | ce1+ce2] (h + shortcut(x), diff_model.py:103) */
     int ce1, ce2;
+    int ld1, ld2;                       /* pixel stride of x1 / x2 in elements, 0 = c1 / c2.  ld < c lets a source
+                                           with ld channels (a multiple of 16 bytes) be read as whole 128-byte slabs:
+                                           the weights of channels [ld, c) must be zero (they meet the next pixel's
+                                           data, or zeros past the end of the buffer) -- 32-channel bf16 layers of
+                                           CSPDarkUnet (model/networks/cspdarkunet.py:24-29)                        */
 } advs_conv_args;
 int advs_conv2d(const advs_conv_args* a, void* stream);
 int advs_conv_set_tile(int tile);       /* tuning hook: non-zero overrides every call's tile  */
@@ -118,6 +127,9 @@ int advs_maxpool2(const void* x, void* y, int b, int h, int w, int c, int dtype,
  * (block.py:66,86-87): skip [b][2h][2w][c1], x [b][h][w][c2] -> y [b][2h][2w][c1+c2].          */
 int advs_concat_upsample2x(const void* skip, const void* x, void* y, int b, int h, int w, int c1, int c2,
                            int dtype, void* stream);
+/* Same with Upsample(scale 2, mode="nearest") -- CSPDarkUpBlock (block.py:116,127-128).           */
+int advs_concat_nearest2x(const void* skip, const void* x, void* y, int b, int h, int w, int c1, int c2,
+                          int dtype, void* stream);
 /* nn.LayerNorm([c]) over the last axis of [rows][c] (model/modules/attention.py:25,27: eps 1e-5; HF ViT: 1e-12). */
 int advs_layernorm(const void* x, const float* gamma, const float* beta, void* y, long long rows, int c,
                    float eps, int dtype, void* stream);
@@ -127,11 +139,11 @@ int advs_layernorm(const void* x, const float* gamma, const float* beta, void* y
  * (AttentionBlock.forward, diff_model.py:120-125; nn.MultiheadAttention core,
  * model/modules/attention.py:50).  qkv is [b][n][ld] (row = token); head hd takes
  * q/k/v at column q_off/k_off/v_off + hd*head_stride, d columns each.  out is [b][n][heads*d].
- * n multiple of 32, d multiple of 16, d <= 128.                                          */
+ * Any n >= 1; d a multiple of 8 (bf16) or 4 (f32), d <= 128.                             */
 int advs_attention(const void* qkv, void* out, int b, int n, int heads, int d, int ld,
                    int q_off, int k_off, int v_off, int head_stride, int dtype, void* stream);
 
-/* Token axis padded to a multiple of 64 (ViT: 197 tokens in rows of 256): keys >= n_valid are masked.  */
+/* Token axis padded (ViT: 197 tokens in rows of 256): keys >= n_valid are masked.  */
 int advs_attention_masked(const void* qkv, void* out, int b, int n, int n_valid, int heads, int d, int ld,
                           int q_off, int k_off, int v_off, int head_stride, int dtype, void* stream);
 

@@ -1,0 +1,86 @@
+"""Network- and sampler-level parity of CSPDarkUnet (generate()'s second --network) on the MI355X: vs the
+golden vectors of the reference and vs the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from advshadow_amd.model.networks.cspdarkunet import CSPDarkUnet  # noqa: E402
+from advshadow_amd.model.samples.ddim import DDIMDiffusion  # noqa: E402
+from oracle import cspdark as oc  # noqa: E402
+from oracle import lineage_a as oa  # noqa: E402
+
+CASES = {"silu": (3, "silu"), "lrelu": (4, "lrelu")}
+
+
+def make(tag, **kw):
+    seed, act = CASES[tag]
+    torch.manual_seed(seed)
+    return CSPDarkUnet(num_classes=37, image_size=64, act=act, device="cuda", **kw).to("cuda").eval()
+
+
+def wrap_diff(a, b):
+    d = (a.astype(np.int16) - b.astype(np.int16)) % 256
+    return np.minimum(d, 256 - d)
+
+
+def test_state_dict_keys_match_reference(golden):
+    g = golden("cspdark_silu.npz")
+    net = make("silu")
+    sd = net.state_dict()
+    assert sorted(sd.keys()) == list(g["sd_keys"])
+    mine = np.array([[float(sd[k].double().sum().cpu()), float(sd[k].double().abs().sum().cpu())] for k in g["sd_keys"]])
+    assert np.allclose(mine, g["sd_digest"], rtol=1e-6, atol=1e-6)      # same seeded construction order
+
+
+@pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("tag", list(CASES))
+def test_forward_fp32_vs_golden(golden, tag, graph):
+    g = golden(f"cspdark_{tag}.npz")
+    net = make(tag, use_graph=graph)
+    x, t, y = (torch.from_numpy(g[k]).cuda() for k in ("x", "t", "y"))
+    for _ in range(2):
+        assert np.abs(net(x, t, y).cpu().numpy() - g["eps_cond"]).max() < 1e-4
+        assert np.abs(net(x, t).cpu().numpy() - g["eps_uncond"]).max() < 1e-4
+
+
+def test_sample_fp32_vs_golden(golden):
+    g = golden("cspdark_silu.npz")
+    net = make("silu")
+    diff = DDIMDiffusion(sample_steps=10, img_size=64, device="cuda")
+    out = diff.sample(net, 2, labels=torch.from_numpy(g["sample_labels"]).cuda(), cfg_scale=3,
+                      x_T=torch.from_numpy(g["sample_xT"]))
+    assert out.dtype == torch.uint8 and out.is_cuda
+    d = wrap_diff(out.cpu().numpy(), g["sample_cfg3"])
+    assert d.max() <= 1 and (d > 0).mean() < 0.01, (d.max(), (d > 0).mean())
+
+
+def test_sample_float_vs_oracle_1e3():
+    """The float trajectory end point against the CPU oracle: <= 1e-3 per pixel (north_star)."""
+    net = make("silu")
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    g = torch.Generator().manual_seed(77)
+    xT = torch.randn(2, 3, 64, 64, generator=g)
+    labels = torch.tensor([4, 21])
+    ref = oa.ddim_sample(lambda x, t, y: oc.cspdarkunet_forward(sd, x, t, y), xT, labels=labels, cfg_scale=3,
+                         sample_steps=5, to_uint8=False)
+    diff = DDIMDiffusion(sample_steps=5, img_size=64, device="cuda")
+    got = diff.sample(net, 2, labels=labels.cuda(), cfg_scale=3, x_T=xT, return_float=True).cpu()
+    assert (got - ref).abs().max().item() < 1e-3
+
+
+def test_forward_bf16_close(golden):
+    """Default channels in bf16: the 32-channel layers go through the half-slab path (ld1 = 32, K = 64) and
+    sa8 through 8-channel heads."""
+    g = golden("cspdark_silu.npz")
+    net = make("silu", compute_dtype="bf16")
+    x, t, y = (torch.from_numpy(g[k]).cuda() for k in ("x", "t", "y"))
+    err = np.abs(net(x, t, y).cpu().numpy() - g["eps_cond"])
+    assert err.max() < 0.15 and err.mean() < 0.02, (err.max(), err.mean())
+
+
+def test_wrong_image_size_is_rejected():
+    net = make("silu")
+    with pytest.raises(ValueError):
+        net(torch.zeros(1, 3, 128, 128, device="cuda"), torch.zeros(1, dtype=torch.long, device="cuda"))

@@ -402,3 +402,85 @@ def test_conv2d_with_extra_1x1_operand(dt, tile, two):
     op.go()
     err = (nchw(y) - ref).abs().max().item()
     assert err < tol(dt, 3e-5, 5e-2), err
+
+
+# ------------------------------------------------------------------------------ CSPDarkUnet additions
+@pytest.mark.parametrize("tile", [0, 1, 4, 10])
+@pytest.mark.parametrize("case", [
+    # B, H, W, C1, C2, Cout, k, stride : 32-channel bf16 sources = half a 128-byte slab (ld < c)
+    (2, 16, 16, 32, 0, 32, 3, 1), (2, 16, 16, 32, 0, 64, 3, 2), (1, 8, 8, 32, 0, 96, 1, 1),
+    (2, 8, 8, 32, 32, 64, 1, 1), (1, 16, 32, 96, 32, 64, 3, 1), (1, 5, 7, 32, 0, 32, 1, 1),
+])
+def test_conv2d_half_slab_sources_bf16(case, tile):
+    B, H, W, C1, C2, Cout, k, stride = case
+    if tile == 10 and not (k == 3 and stride == 1 and H % 16 == 0 and W % 16 == 0):
+        pytest.skip("halo kernel: 3x3 stride 1, H and W multiples of 16")
+    pad = 1 if k == 3 else 0
+    x1 = bf16_round(rnd(B, C1, H, W, seed=61))
+    x2 = bf16_round(rnd(B, C2, H, W, seed=62)) if C2 else None
+    w = rnd(Cout, C1 + C2, k, k, seed=63, scale=1.0 / math.sqrt((C1 + C2) * k * k))
+    ref = F.conv2d(x1 if x2 is None else torch.cat([x1, x2], 1), bf16_round(w), None, stride=stride, padding=pad)
+    op = OneOp("bf16", B)
+    wp = pack_conv_weight(w.to(dev()), dtype_code("bf16"), sources=(C1, C2) if C2 else None)
+    y = op.b.conv(nhwc(x1, "bf16"), wp, Cout, x2=nhwc(x2, "bf16") if C2 else None, ksize=k, stride=stride, pad=pad, tile=tile)
+    op.go()
+    err = (nchw(y) - ref).abs().max().item()
+    assert err < 4e-2, err
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("case", [(2, 16, 4, 8, "a"), (1, 4, 4, 16, "a"), (1, 100, 2, 8, "b"), (2, 4096, 4, 8, "a"), (1, 16, 4, 128, "a")])
+def test_attention_short_sequences_and_narrow_heads(case, dt):
+    """CSPDarkUnet: sa4 has 16 tokens at 64x64 input, sa8 has 8-channel heads (cspdarkunet.py:50-78)."""
+    B, N, heads, d, lay = case
+    C = heads * d
+    qkv = rnd(B, N, 3 * C, seed=64)
+    if dt == "bf16":
+        qkv = bf16_round(qkv)
+    if lay == "b":
+        t = qkv.view(B, N, heads, 3, d)
+        q, k, v = t[:, :, :, 0], t[:, :, :, 1], t[:, :, :, 2]
+        offs = (0, d, 2 * d, 3 * d)
+    else:
+        t = qkv.view(B, N, 3, heads, d)
+        q, k, v = t[:, :, 0], t[:, :, 1], t[:, :, 2]
+        offs = (0, C, 2 * C, d)
+    q, k, v = (u.permute(0, 2, 1, 3) for u in (q, k, v))
+    ref = (torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(d), dim=-1) @ v).permute(0, 2, 1, 3).reshape(B, N, C)
+    op = OneOp(dt, B)
+    x = qkv.view(B, 1, N, 3 * C).to(dev(), torch.bfloat16 if dt == "bf16" else torch.float32)
+    y = op.b.attention(x, heads, d, *offs)
+    op.go()
+    err = (y.float().cpu().view(B, N, C) - ref).abs().max().item()
+    assert err < tol(dt, 2e-5, 3e-2), err
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("shape", [(2, 8, 8, 32, 32), (1, 4, 6, 128, 64), (1, 1, 1, 64, 64)])
+def test_concat_nearest2x(shape, dt):
+    B, h, w, C1, C2 = shape
+    skip, x = rnd(B, C1, 2 * h, 2 * w, seed=65), rnd(B, C2, h, w, seed=66)
+    if dt == "bf16":
+        skip, x = bf16_round(skip), bf16_round(x)
+    ref = torch.cat([skip, F.interpolate(x, scale_factor=2, mode="nearest")], 1)
+    op = OneOp(dt, B)
+    y = op.b.concat_nearest2x(nhwc(skip, dt), nhwc(x, dt))
+    op.go()
+    assert torch.equal(nchw(y), ref)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_groupnorm_residual_after_activation(dt):
+    """Bottleneck: act(gn(conv)) + x (module.py:42-47), with the block's emb add in the same pass."""
+    B, C, H, W = 2, 64, 8, 8
+    x, r, emb = rnd(B, C, H, W, seed=67), rnd(B, C, H, W, seed=68), rnd(B, C, seed=69)
+    g, b = rnd(C, seed=70) + 1, rnd(C, seed=71)
+    xr, rr = (bf16_round(x), bf16_round(r)) if dt == "bf16" else (x, r)
+    ref = F.silu(F.group_norm(xr, 1, g, b, eps=1e-5)) + emb[:, :, None, None] + rr
+    op = OneOp(dt, B)
+    e = emb.to(dev())
+    y = op.b.groupnorm(nhwc(x, dt), g.to(dev()), b.to(dev()), 1, act="silu", residual=nhwc(r, dt),
+                       residual_after_act=True, chan_add=e, chan_add_stride=C)
+    op.go()
+    err = (nchw(y) - ref).abs().max().item()
+    assert err < tol(dt, 2e-5, 6e-2), err
