@@ -116,6 +116,7 @@ class Builder:
         self.stats = {}               # data_ptr of a conv output -> (stats tensor, row blocks per image)
         nb = self.lib.advs_groupnorm_scratch_bytes(batch, 64)
         self.gn_scratch = torch.empty(nb, dtype=torch.uint8, device=device)
+        self.plan.keep.append(self.gn_scratch)   # the plan outlives the Builder: every launch refers to this scratch
 
     # ---- buffers
     def buf(self, shape, dtype=None):

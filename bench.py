@@ -91,14 +91,27 @@ def conv_traffic_from_profiles():
                                 "note": "PMC FETCH_SIZE x2 + WRITE_SIZE, averaged over the forward's conv launches"}
 
 
+def host_cores():
+    """Threads for the CPU baseline: the process's affinity mask, capped by the cgroup CPU quota when there is
+    one and otherwise by the GPU box's per-GPU CPU share (16): more threads than granted CPUs only spin."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            return max(1, min(n, int(int(quota) / int(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return min(n, 16)
+
+
 def cpu_baseline(size, ddim_steps, budget_s=20.0):
     """The CPU oracle (oracle/lineage_b.py, torch-CPU fp32) on the host cores: B=1 forwards of the
     same network at the same resolution, extrapolated to a full ddim_steps-step image."""
     from oracle import lineage_b as ob
-    try:
-        cores = len(os.sched_getaffinity(0))                    # the cores this process may use
-    except AttributeError:
-        cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     hp = ob.hparams()
     sd = ob.init_state_dict(0, hp)

@@ -43,6 +43,28 @@ def test_generate_writes_reference_file_set(tmp_path):
     assert Image.open(os.path.join(out_dir, "df.png")).size == (2 * 66 + 2, 66 + 2)
 
 
+def test_generate_with_cspdarkunet_and_plms(tmp_path):
+    """--network cspdarkunet (utils/initializer.py:90-91) with --sample plms, unconditional, jpg output."""
+    from oracle import cspdark as oc
+    sd = oc.init_state_dict(3, num_classes=None)
+    wpath = str(tmp_path / "csp.pt")
+    torch.save({"model": sd, "network": "cspdarkunet", "image_size": 64, "conditional": False, "act": "silu",
+                "num_classes": None, "sample": "plms"}, wpath)
+    g = torch.Generator().manual_seed(9)
+    xT = torch.randn(1, 3, 64, 64, generator=g)
+    args = argparse.Namespace(weight_path=wpath, conditional=False, network="unet", image_size=64, num_classes=10,
+                              act="silu", generate_name="csp", sample="plms", num_images=1, use_ema=False,
+                              image_format="png", result_path=str(tmp_path / "vis"), class_name=-1, cfg_scale=3,
+                              sample_steps=4, x_T=xT)
+    out_dir = generate(args)
+    assert sorted(os.listdir(out_dir)) == ["csp.png", "csp_0.png"]
+    ref = oa.plms_sample(lambda x, t, y: oc.cspdarkunet_forward(sd, x, t, y), xT, sample_steps=4).numpy()
+    got = np.asarray(Image.open(os.path.join(out_dir, "csp_0.png"))).transpose(2, 0, 1)
+    d = (got.astype(np.int16) - ref[0].astype(np.int16)) % 256
+    d = np.minimum(d, 256 - d)
+    assert d.max() <= 1 and (d > 0).mean() < 0.01
+
+
 def test_bare_state_dict_and_shape_filter(tmp_path):
     from advshadow_amd.utils.checkpoint import load_ckpt
     sd = oa.init_state_dict(2, num_classes=37)

@@ -96,7 +96,12 @@ def test_pack_conv_weight(dt):
     p = pack_conv_weight(w.to(dev()), dtype_code(dt)).float().cpu()
     ref = w.permute(0, 2, 3, 1)
     ref = bf16_round(ref) if dt == "bf16" else ref
-    assert torch.equal(p, ref.contiguous())
+    slab = 64 if dt == "bf16" else 32                      # input channels are zero-padded to whole 128-byte slabs
+    assert p.shape == (6, 3, 3, slab)
+    assert torch.equal(p[..., :5], ref.contiguous()) and not p[..., 5:].any()
+    w2 = rnd(4, 2 * slab, 1, 1, seed=10)
+    p2 = pack_conv_weight(w2.to(dev()), dtype_code(dt)).float().cpu()
+    assert torch.equal(p2, (bf16_round(w2) if dt == "bf16" else w2).permute(0, 2, 3, 1).contiguous())
 
 
 @pytest.mark.parametrize("dt", DTS)
