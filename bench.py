@@ -30,7 +30,7 @@ PEAK_MFMA_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}     # MI355X_MICROARCH.md: de
 
 def conv_profile(eng, reps=2):
     """Time every launch of the plan with HIP events on the engine's stream (eager replay) and
-    return per-kernel totals: {entry point: [launches, total ms, algorithmic flops]}."""
+    return per-kernel totals: {entry point: [launches, total ms, algorithmic flops, algorithmic bytes]}."""
     from advshadow_amd import _lib
     lib = _lib.load()
     s = eng.stream.cuda_stream
@@ -53,7 +53,7 @@ def conv_profile(eng, reps=2):
         for i, (fn, args) in enumerate(ops):
             ms = C.c_float()
             _lib.check(lib.advs_event_elapsed_ms(evs[i], evs[i + 1], C.byref(ms)))
-            t = totals.setdefault(fn.__name__, [0, 0.0, 0.0])
+            t = totals.setdefault(fn.__name__, [0, 0.0, 0.0, 0.0])
             t[0] += 1
             t[1] += ms.value
             if fn.__name__ == "advs_conv2d":
@@ -61,13 +61,19 @@ def conv_profile(eng, reps=2):
                 hl, wl = (a.h * 2, a.w_ * 2) if a.upsample else (a.h, a.w_)
                 ho = (hl + 2 * a.pad - a.ksize) // a.stride + 1
                 wo = (wl + 2 * a.pad - a.ksize) // a.stride + 1
-                t[2] += 2.0 * a.b * ho * wo * a.cout * a.ksize * a.ksize * (a.c1 + a.c2)
+                # the fused shortcut (extra 1x1 operand) is the reference's separate Conv2d (diff_model.py:89,103)
+                k_total = a.ksize * a.ksize * (a.c1 + a.c2) + a.ce1 + a.ce2
+                t[2] += 2.0 * a.b * ho * wo * a.cout * k_total
+                esz = 2 if a.dtype == 1 else 4
+                t[3] += esz * (a.b * a.h * a.w_ * (a.c1 + a.c2) + a.cout * k_total
+                               + a.b * ho * wo * (a.cout * (2 if a.residual else 1) + a.ce1 + a.ce2))
     for e in evs:
         lib.advs_event_destroy(e)
     for t in totals.values():
         t[0] //= reps
         t[1] /= reps
         t[2] /= reps
+        t[3] /= reps
     return totals
 
 
@@ -87,8 +93,10 @@ def conv_traffic_from_profiles():
             n += v["launches"]
             fetch += v["launches"] * v["FETCH_SIZE_KB_avg"] * 1024.0 * 2.0
             write += v["launches"] * (v["WRITE_SIZE_KB_avg"] or 0.0) * 1024.0
-    return None if n == 0 else {"bytes_per_launch": (fetch + write) / n, "source": os.path.basename(files[-1]),
-                                "note": "PMC FETCH_SIZE x2 + WRITE_SIZE, averaged over the forward's conv launches"}
+    if n == 0:
+        return None
+    return {"bytes_per_launch": (fetch + write) / n, "source": os.path.basename(files[-1]),
+            "note": "PMC FETCH_SIZE x2 + WRITE_SIZE, averaged over the forward's conv launches"}
 
 
 def host_cores():
@@ -210,10 +218,13 @@ def main():
         c = tot["advs_conv2d"]
         fwd_ms = sum(t[1] for t in tot.values())
         ach = c[2] / (c[1] * 1e-3) / 1e12
+        tr = conv_traffic_from_profiles()
         peak = PEAK_MFMA_TFLOPS[args.dtype]
         line["roofline"] = {"bound": "mfma", "kernel": "advs_conv2d (conv3x3_halo_kernel + conv_igemm_kernel)",
                             "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                            "traffic": conv_traffic_from_profiles(),
+                            "traffic": tr["bytes_per_launch"] if tr else None, "traffic_unit": "bytes/launch",
+                            "traffic_source": (tr["source"] + ": " + tr["note"]) if tr else None,
+                            "algorithmic_bytes_per_launch": c[3] / c[0],
                             "launches_per_forward": c[0], "avg_launch_ms": c[1] / c[0],
                             "algorithmic_gflop_per_launch": c[2] / c[0] / 1e9,
                             "forward_ms_by_kernel": {k: round(v[1], 3) for k, v in sorted(tot.items())},
@@ -223,6 +234,7 @@ def main():
     if rank == 0:
         print(json.dumps(line))
     if world > 1:
+        dist.barrier()                                          # rank 0 is still profiling: leave together
         dist.destroy_process_group()
 
 
