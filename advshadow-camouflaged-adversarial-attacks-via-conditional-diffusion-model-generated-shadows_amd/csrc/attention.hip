@@ -23,6 +23,7 @@ struct AttnP {
 
 template <typename T> struct AMma;
 template <> struct AMma<BF16> { static constexpr int ESZ = 2; };
+template <> struct AMma<F16> { static constexpr int ESZ = 2; };
 template <> struct AMma<float> { static constexpr int ESZ = 4; };
 
 template <typename T, int DT>
@@ -106,8 +107,7 @@ attn_kernel(const AttnP p) {
                 if (s < dsteps) {
                     const u32x4 kf = *(const u32x4*)(sK + (kb * 32 + l31) * KS + s * 32 + lh * 16);
                     if (ESZ == 2) {
-                        st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf),
-                                                                        __builtin_bit_cast(bf16x8, qf[s]), st[kb], 0, 0, 0);
+                        if constexpr (ESZ == 2) st[kb] = mma16<T>(kf, qf[s], st[kb]);
                     } else {
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
@@ -151,16 +151,14 @@ attn_kernel(const AttnP p) {
                     u32x4 pf;
 #pragma unroll
                     for (int w = 0; w < 4; ++w)
-                        pf[w] = (unsigned)f32_to_bf16(st[kb][8 * s2 + 2 * w]) |
-                                ((unsigned)f32_to_bf16(st[kb][8 * s2 + 2 * w + 1]) << 16);
+                        if constexpr (ESZ == 2) pf[w] = pack2<T>(st[kb][8 * s2 + 2 * w], st[kb][8 * s2 + 2 * w + 1]);
 #pragma unroll
                     for (int t = 0; t < DT; ++t) {
                         const char* vr = sV + (t * 32 + l31) * VS + (kb * 32 + 16 * s2 + 4 * lh) * 2;
                         const u32x2 lo = *(const u32x2*)vr;            // keys +0..3
                         const u32x2 hi = *(const u32x2*)(vr + 16);     // keys +8..11
                         const u32x4 vf = u32x4{lo[0], lo[1], hi[0], hi[1]};
-                        o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf),
-                                                                      __builtin_bit_cast(bf16x8, pf), o[t], 0, 0, 0);
+                        if constexpr (ESZ == 2) o[t] = mma16<T>(vf, pf, o[t]);
                     }
                 }
             } else {
@@ -219,7 +217,7 @@ static int attention_impl(const void* qkv, void* out, int b, int n, int n_valid,
                           int q_off, int k_off, int v_off, int head_stride, int dtype, void* stream) {
     ADVS_REQUIRE(qkv && out && b > 0 && n > 0 && heads > 0 && d > 0, "attention: bad args");
     ADVS_REQUIRE(n_valid > 0 && n_valid <= n, "attention: n_valid=%d out of range", n_valid);
-    const int vec = dtype == ADVS_BF16 ? 8 : 4;
+    const int vec = dtype == ADVS_F32 ? 4 : 8;
     ADVS_REQUIRE(d % vec == 0 && d <= 128, "attention: d=%d must be a multiple of %d and <= 128", d, vec);
     ADVS_REQUIRE(ld % vec == 0 && q_off % vec == 0 && k_off % vec == 0 && v_off % vec == 0 && head_stride % vec == 0,
                  "attention: offsets must keep 16-byte alignment");
@@ -228,8 +226,8 @@ static int attention_impl(const void* qkv, void* out, int b, int n, int n_valid,
     p.B = b; p.N = n; p.heads = heads; p.d = d; p.ld = ld;
     p.q_off = q_off; p.k_off = k_off; p.v_off = v_off; p.head_stride = head_stride; p.n_valid = n_valid;
     p.scale_log2e = (float)(1.4426950408889634 / sqrt((double)d));
-    if (dtype == ADVS_BF16) return attn_launch<BF16>(p, (hipStream_t)stream);
-    return attn_launch<float>(p, (hipStream_t)stream);
+    ADVS_SWITCH_T(dtype, return attn_launch<T>(p, (hipStream_t)stream));
+    return ADVS_ERR_ARG;                    // not reached
 }
 
 extern "C" int advs_attention(const void* qkv, void* out, int b, int n, int heads, int d, int ld,

@@ -8,6 +8,7 @@
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) short bf16x8;   // 8 bf16 = one MFMA A/B fragment
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8; // 8 fp16 = one MFMA A/B fragment
 typedef __attribute__((ext_vector_type(4))) short bf16x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
@@ -22,15 +23,20 @@ void advs_set_error(const char* fmt, ...);
     if (e__ != hipSuccess) ADVS_FAIL(ADVS_ERR_HIP, "%s: %s", #call, hipGetErrorString(e__)); } while (0)
 
 // ---- element types ----------------------------------------------------------
-// Activations and GEMM weights are either f32 (parity mode, exact-f32 MFMA) or bf16
-// (throughput mode, bf16 MFMA with f32 accumulation).  Storage type of bf16 is a raw u16.
+// Activations and GEMM weights are f32 (parity mode, exact-f32 MFMA), bf16 or fp16 (throughput modes,
+// 16-bit MFMA with f32 accumulation; fp16 is the dtype BASELINE.json's config 4 names).  The 16-bit
+// storage types are raw u16.
 struct BF16 { unsigned short v; };
+struct F16 { unsigned short v; };
 
 __device__ __forceinline__ float bf16_to_f32(unsigned short u) { return __uint_as_float(((unsigned)u) << 16); }
 __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
     __bf16 b = (__bf16)f;                       // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
     return __builtin_bit_cast(unsigned short, b);
 }
+
+__device__ __forceinline__ float f16_to_f32(unsigned short u) { return (float)__builtin_bit_cast(_Float16, u); }
+__device__ __forceinline__ unsigned short f32_to_f16(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }   // RNE
 
 template <typename T> struct Elt;
 template <> struct Elt<float> {
@@ -42,6 +48,12 @@ template <> struct Elt<BF16> {
     static constexpr int VEC = 8;
     __device__ static __forceinline__ float ld(const BF16* p) { return bf16_to_f32(p->v); }
     __device__ static __forceinline__ void st(BF16* p, float v) { p->v = f32_to_bf16(v); }
+};
+
+template <> struct Elt<F16> {
+    static constexpr int VEC = 8;
+    __device__ static __forceinline__ float ld(const F16* p) { return f16_to_f32(p->v); }
+    __device__ static __forceinline__ void st(F16* p, float v) { p->v = f32_to_f16(v); }
 };
 
 // 16-byte vector <-> floats
@@ -57,6 +69,13 @@ template <> __device__ __forceinline__ void unpack16<BF16>(const u32x4& raw, flo
         out[2 * i + 1] = __uint_as_float(raw[i] & 0xffff0000u);
     }
 }
+template <> __device__ __forceinline__ void unpack16<F16>(const u32x4& raw, float* out) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        out[2 * i] = f16_to_f32((unsigned short)(raw[i] & 0xffffu));
+        out[2 * i + 1] = f16_to_f32((unsigned short)(raw[i] >> 16));
+    }
+}
 template <typename T> __device__ __forceinline__ u32x4 pack16(const float* in);
 template <> __device__ __forceinline__ u32x4 pack16<float>(const float* in) {
     u32x4 r;
@@ -70,6 +89,26 @@ template <> __device__ __forceinline__ u32x4 pack16<BF16>(const float* in) {
     for (int i = 0; i < 4; ++i)
         r[i] = (unsigned)f32_to_bf16(in[2 * i]) | ((unsigned)f32_to_bf16(in[2 * i + 1]) << 16);
     return r;
+}
+
+template <> __device__ __forceinline__ u32x4 pack16<F16>(const float* in) {
+    u32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        r[i] = (unsigned)f32_to_f16(in[2 * i]) | ((unsigned)f32_to_f16(in[2 * i + 1]) << 16);
+    return r;
+}
+// two f32 -> one packed pair of 16-bit T
+template <typename T> __device__ __forceinline__ unsigned pack2(float lo, float hi);
+template <> __device__ __forceinline__ unsigned pack2<BF16>(float lo, float hi) { return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16); }
+template <> __device__ __forceinline__ unsigned pack2<F16>(float lo, float hi) { return (unsigned)f32_to_f16(lo) | ((unsigned)f32_to_f16(hi) << 16); }
+// K = 16 MFMA on one 16-byte fragment per operand
+template <typename T> __device__ __forceinline__ f32x16 mma16(const u32x4& a, const u32x4& b, const f32x16& c);
+template <> __device__ __forceinline__ f32x16 mma16<BF16>(const u32x4& a, const u32x4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x16 mma16<F16>(const u32x4& a, const u32x4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
 // SiLU for values that are rounded to bf16 right after: v_exp_f32 + v_rcp_f32 (each ~1 ulp) instead of
@@ -95,9 +134,20 @@ template <> __device__ __forceinline__ float apply_act_t<float>(float v, int act
 template <> __device__ __forceinline__ float apply_act_t<BF16>(float v, int act) {
     return act == ADVS_ACT_SILU ? silu_fast(v) : apply_act(v, act);
 }
+template <> __device__ __forceinline__ float apply_act_t<F16>(float v, int act) {
+    return act == ADVS_ACT_SILU ? silu_fast(v) : apply_act(v, act);
+}
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
-static inline size_t dtype_size(int dt) { return dt == ADVS_BF16 ? 2 : 4; }
+static inline size_t dtype_size(int dt) { return dt == ADVS_F32 ? 4 : 2; }
+static inline bool dtype_ok(int dt) { return dt == ADVS_F32 || dt == ADVS_BF16 || dt == ADVS_F16; }
+// Instantiate `...` with T = float / BF16 / F16 according to the runtime dtype code.
+#define ADVS_SWITCH_T(dt, ...)                                              \
+    do {                                                                    \
+        if ((dt) == ADVS_BF16) { using T = BF16; __VA_ARGS__; }             \
+        else if ((dt) == ADVS_F16) { using T = F16; __VA_ARGS__; }          \
+        else { using T = float; __VA_ARGS__; }                              \
+    } while (0)
 
 // 128 zero bytes every lane may read instead of an out-of-image / out-of-range row.
 const void* advs_zero_page();

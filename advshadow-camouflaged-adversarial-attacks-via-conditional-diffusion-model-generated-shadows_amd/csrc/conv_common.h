@@ -45,9 +45,11 @@ template <typename T> struct Mma;
 template <> struct Mma<BF16> {
     static constexpr int ESZ = 2;
     // one 16-byte fragment per operand = K of 16 (two lane halves x 8)
-    __device__ static __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) {
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-    }
+    __device__ static __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) { c = mma16<BF16>(a, b, c); }
+};
+template <> struct Mma<F16> {
+    static constexpr int ESZ = 2;
+    __device__ static __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) { c = mma16<F16>(a, b, c); }
 };
 template <> struct Mma<float> {
     static constexpr int ESZ = 4;

@@ -81,10 +81,7 @@ extern "C" int advs_conv3x3_first(const float* x, const float* w, const float* b
     const long long nruns = (long long)b * h * ((wd + CF_PX - 1) / CF_PX);
     const int gpb = 256 / (cout / 8);
     int grid = (int)((nruns + gpb - 1) / gpb < 16384 ? (nruns + gpb - 1) / gpb : 16384);
-    if (dtype == ADVS_BF16)
-        conv3x3_first_kernel<BF16><<<grid, 256, lds, (hipStream_t)stream>>>(x, w, bias, (BF16*)y, b, cin, h, wd, cout);
-    else
-        conv3x3_first_kernel<float><<<grid, 256, lds, (hipStream_t)stream>>>(x, w, bias, (float*)y, b, cin, h, wd, cout);
+    ADVS_SWITCH_T(dtype, conv3x3_first_kernel<T><<<grid, 256, lds, (hipStream_t)stream>>>(x, w, bias, (T*)y, b, cin, h, wd, cout));
     ADVS_CHECK_LAUNCH("conv3x3_first");
     return ADVS_OK;
 }
@@ -173,16 +170,13 @@ extern "C" int advs_conv_last(const void* x, const float* w, const float* bias, 
     ADVS_REQUIRE(x && w && y && b > 0 && h > 0 && wd > 0, "conv_last: bad args");
     ADVS_REQUIRE(cout >= 1 && cout <= 4, "conv_last: cout=%d must be <= 4", cout);
     ADVS_REQUIRE(ksize == 1 || ksize == 3, "conv_last: ksize %d unsupported", ksize);
-    const int vec = dtype == ADVS_BF16 ? 8 : 4;
+    const int vec = dtype == ADVS_F32 ? 4 : 8;
     ADVS_REQUIRE(cin % vec == 0, "conv_last: cin=%d must be a multiple of %d", cin, vec);
     const size_t lds = (size_t)ksize * ksize * cin * 4 * sizeof(float);
     ADVS_REQUIRE(lds <= 65536, "conv_last: cin=%d too large", cin);
     const long long nruns = (long long)b * h * ((wd + CL_PX - 1) / CL_PX);
     int grid = (int)((nruns + 15) / 16 < 16384 ? (nruns + 15) / 16 : 16384);
-    if (dtype == ADVS_BF16)
-        conv_last_kernel<BF16><<<grid, 256, lds, (hipStream_t)stream>>>((const BF16*)x, w, bias, y, b, cin, h, wd, cout, ksize);
-    else
-        conv_last_kernel<float><<<grid, 256, lds, (hipStream_t)stream>>>((const float*)x, w, bias, y, b, cin, h, wd, cout, ksize);
+    ADVS_SWITCH_T(dtype, conv_last_kernel<T><<<grid, 256, lds, (hipStream_t)stream>>>((const T*)x, w, bias, y, b, cin, h, wd, cout, ksize));
     ADVS_CHECK_LAUNCH("conv_last");
     return ADVS_OK;
 }

@@ -232,6 +232,6 @@ static int halo_launch(ConvKP& p, hipStream_t st) {
 
 int conv_halo_dispatch(ConvKP& p, int dtype, hipStream_t st) {
     ADVS_REQUIRE(conv_halo_eligible(p), "conv2d: tile 10 (halo kernel) needs 3x3 stride 1 pad 1, no upsample / extra operand, H and W multiples of 16");
-    if (dtype == ADVS_BF16) return halo_launch<BF16>(p, st);
-    return halo_launch<float>(p, st);
+    ADVS_SWITCH_T(dtype, return halo_launch<T>(p, st));
+    return ADVS_ERR_ARG;                    // not reached
 }

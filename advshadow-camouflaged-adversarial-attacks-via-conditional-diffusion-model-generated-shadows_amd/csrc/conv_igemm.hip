@@ -374,7 +374,7 @@ extern "C" int advs_conv2d(const advs_conv_args* a, void* stream) {
     ADVS_REQUIRE((a->ce1 == 0) == (a->e1 == nullptr) && (a->ce2 == 0) == (a->e2 == nullptr) && (a->e1 || !a->e2),
                  "conv2d: extra operand pointers/channels mismatch");
     ADVS_REQUIRE(!a->e1 || a->stride == 1, "conv2d: the extra 1x1 operand needs stride 1");
-    const int esz = a->dtype == ADVS_BF16 ? 2 : 4;
+    const int esz = a->dtype == ADVS_F32 ? 4 : 2;
     const int bke = SLAB / esz;
     ADVS_REQUIRE(a->c1 % bke == 0 && a->c2 % bke == 0 && a->ce1 % bke == 0 && a->ce2 % bke == 0,
                  "conv2d: channels (%d,%d | %d,%d) must be multiples of %d", a->c1, a->c2, a->ce1, a->ce2, bke);
@@ -420,6 +420,6 @@ extern "C" int advs_conv2d(const advs_conv_args* a, void* stream) {
         else ADVS_REQUIRE(a->stats_rows == wm, "conv2d: stats buffer sized for %d-row blocks but the tile uses %d", a->stats_rows, wm);
     }
     if (tile == 10) return conv_halo_dispatch(p, a->dtype, (hipStream_t)stream);
-    if (a->dtype == ADVS_BF16) return conv_dispatch<BF16>(p, tile, (hipStream_t)stream);
-    return conv_dispatch<float>(p, tile, (hipStream_t)stream);
+    ADVS_SWITCH_T(a->dtype, return conv_dispatch<T>(p, tile, (hipStream_t)stream));
+    return ADVS_ERR_ARG;                    // not reached
 }

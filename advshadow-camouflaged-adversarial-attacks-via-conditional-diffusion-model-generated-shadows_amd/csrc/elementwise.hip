@@ -22,10 +22,7 @@ extern "C" int advs_pack_conv_weight(const float* w, void* out, int cout, int ci
     ADVS_REQUIRE(w && out && cout > 0 && cin > 0 && r > 0 && s > 0, "pack_conv_weight: bad args");
     size_t total = (size_t)cout * cin * r * s;
     int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    if (dtype == ADVS_BF16)
-        pack_conv_weight_kernel<BF16><<<grid, 256, 0, (hipStream_t)stream>>>(w, (BF16*)out, cout, cin, r * s);
-    else
-        pack_conv_weight_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>(w, (float*)out, cout, cin, r * s);
+    ADVS_SWITCH_T(dtype, pack_conv_weight_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>(w, (T*)out, cout, cin, r * s));
     ADVS_CHECK_LAUNCH("pack_conv_weight");
     return ADVS_OK;
 }
@@ -68,16 +65,14 @@ __global__ void layout_kernel(const void* __restrict__ src, void* __restrict__ d
 extern "C" int advs_nchw_f32_to_nhwc(const float* x, void* y, int b, int c, int h, int w, int dtype, void* stream) {
     ADVS_REQUIRE(x && y && b > 0 && c > 0 && h > 0 && w > 0, "nchw_to_nhwc: bad args");
     dim3 grid(cdiv((long long)h * w, 32), cdiv(c, 32), b);
-    if (dtype == ADVS_BF16) layout_kernel<BF16, true><<<grid, 256, 0, (hipStream_t)stream>>>(x, y, c, h * w);
-    else layout_kernel<float, true><<<grid, 256, 0, (hipStream_t)stream>>>(x, y, c, h * w);
+    ADVS_SWITCH_T(dtype, layout_kernel<T, true><<<grid, 256, 0, (hipStream_t)stream>>>(x, y, c, h * w));
     ADVS_CHECK_LAUNCH("nchw_to_nhwc");
     return ADVS_OK;
 }
 extern "C" int advs_nhwc_to_nchw_f32(const void* x, float* y, int b, int c, int h, int w, int dtype, void* stream) {
     ADVS_REQUIRE(x && y && b > 0 && c > 0 && h > 0 && w > 0, "nhwc_to_nchw: bad args");
     dim3 grid(cdiv((long long)h * w, 32), cdiv(c, 32), b);
-    if (dtype == ADVS_BF16) layout_kernel<BF16, false><<<grid, 256, 0, (hipStream_t)stream>>>(x, y, c, h * w);
-    else layout_kernel<float, false><<<grid, 256, 0, (hipStream_t)stream>>>(x, y, c, h * w);
+    ADVS_SWITCH_T(dtype, layout_kernel<T, false><<<grid, 256, 0, (hipStream_t)stream>>>(x, y, c, h * w));
     ADVS_CHECK_LAUNCH("nhwc_to_nchw");
     return ADVS_OK;
 }

@@ -269,14 +269,11 @@ extern "C" int advs_groupnorm(const void* x, const void* x2, const float* gamma,
     const int c = c1 + c2;
     ADVS_REQUIRE(b > 0 && hw > 0 && c > 0 && groups > 0 && groups <= 64 && c % groups == 0,
                  "groupnorm: bad shape b=%d hw=%d c=%d groups=%d", b, hw, c, groups);
-    const int vec = dtype == ADVS_BF16 ? 8 : 4;
+    const int vec = dtype == ADVS_F32 ? 4 : 8;
     ADVS_REQUIRE(c1 % vec == 0 && c2 % vec == 0 && c / vec <= GN_THREADS, "groupnorm: c=%d+%d unsupported for dtype %d", c1, c2, dtype);
     ADVS_REQUIRE((size_t)(GN_THREADS / (c / vec)) * c * 8 <= 65536, "groupnorm: LDS budget exceeded for c=%d", c);
-    if (dtype == ADVS_BF16)
-        return gn_launch<BF16>(x, x2, c1, gamma, beta, residual_in, y, (float*)partials, b, hw, c, groups, act,
-                               chan_add, chan_add_stride, (hipStream_t)stream);
-    return gn_launch<float>(x, x2, c1, gamma, beta, residual_in, y, (float*)partials, b, hw, c, groups, act,
-                            chan_add, chan_add_stride, (hipStream_t)stream);
+    ADVS_SWITCH_T(dtype, return gn_launch<T>(x, x2, c1, gamma, beta, residual_in, y, (float*)partials, b, hw, c, groups, act, chan_add, chan_add_stride, (hipStream_t)stream));
+    return ADVS_ERR_ARG;                    // not reached
 }
 
 // Same as advs_groupnorm, but the per-channel statistics were already emitted by the conv
@@ -291,11 +288,8 @@ extern "C" int advs_groupnorm_stats(const void* x, const void* x2, const float* 
                  "groupnorm_stats: x2/c2/stats2 mismatch");
     const int c = c1 + c2;
     ADVS_REQUIRE(b > 0 && hw > 0 && groups > 0 && groups <= 64 && c % groups == 0, "groupnorm_stats: bad shape");
-    const int vec = dtype == ADVS_BF16 ? 8 : 4;
+    const int vec = dtype == ADVS_F32 ? 4 : 8;
     ADVS_REQUIRE(c1 % vec == 0 && c2 % vec == 0 && c / vec <= GN_THREADS && c <= GNF_MAXC, "groupnorm_stats: c=%d+%d unsupported", c1, c2);
-    if (dtype == ADVS_BF16)
-        return gn_launch<BF16>(x, x2, c1, gamma, beta, residual_in, y, (float*)scratch, b, hw, c, groups, act, chan_add,
-                               chan_add_stride, (hipStream_t)stream, stats1, row_blocks_per_image1, stats2, row_blocks_per_image2);
-    return gn_launch<float>(x, x2, c1, gamma, beta, residual_in, y, (float*)scratch, b, hw, c, groups, act, chan_add,
-                            chan_add_stride, (hipStream_t)stream, stats1, row_blocks_per_image1, stats2, row_blocks_per_image2);
+    ADVS_SWITCH_T(dtype, return gn_launch<T>(x, x2, c1, gamma, beta, residual_in, y, (float*)scratch, b, hw, c, groups, act, chan_add, chan_add_stride, (hipStream_t)stream, stats1, row_blocks_per_image1, stats2, row_blocks_per_image2));
+    return ADVS_ERR_ARG;                    // not reached
 }

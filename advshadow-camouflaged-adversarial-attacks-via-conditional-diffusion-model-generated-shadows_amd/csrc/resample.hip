@@ -35,12 +35,11 @@ __global__ void maxpool2_kernel(const T* __restrict__ x, T* __restrict__ y, int 
 
 extern "C" int advs_maxpool2(const void* x, void* y, int b, int h, int w, int c, int dtype, void* stream) {
     ADVS_REQUIRE(x && y && b > 0 && h > 1 && w > 1 && h % 2 == 0 && w % 2 == 0, "maxpool2: bad shape");
-    const int vec = dtype == ADVS_BF16 ? 8 : 4;
+    const int vec = dtype == ADVS_F32 ? 4 : 8;
     ADVS_REQUIRE(c % vec == 0, "maxpool2: c=%d must be a multiple of %d", c, vec);
     const size_t total = (size_t)b * (h / 2) * (w / 2) * (c / vec);
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    if (dtype == ADVS_BF16) maxpool2_kernel<BF16><<<grid, 256, 0, (hipStream_t)stream>>>((const BF16*)x, (BF16*)y, b, h, w, c);
-    else maxpool2_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>((const float*)x, (float*)y, b, h, w, c);
+    ADVS_SWITCH_T(dtype, maxpool2_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T*)x, (T*)y, b, h, w, c));
     ADVS_CHECK_LAUNCH("maxpool2");
     return ADVS_OK;
 }
@@ -93,14 +92,11 @@ template <bool NEAREST>
 static int concat_up_launch(const char* name, const void* skip, const void* x, void* y, int b, int h, int w, int c1, int c2,
                             int dtype, void* stream) {
     ADVS_REQUIRE(skip && x && y && b > 0 && h > 0 && w > 0, "%s: bad args", name);
-    const int vec = dtype == ADVS_BF16 ? 8 : 4;
+    const int vec = dtype == ADVS_F32 ? 4 : 8;
     ADVS_REQUIRE(c1 % vec == 0 && c2 % vec == 0 && c2 > 0, "%s: channels must be multiples of %d", name, vec);
     const size_t total = (size_t)b * 4 * h * w * ((c1 + c2) / vec);
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    if (dtype == ADVS_BF16)
-        concat_up_kernel<BF16, NEAREST><<<grid, 256, 0, (hipStream_t)stream>>>((const BF16*)skip, (const BF16*)x, (BF16*)y, b, h, w, c1, c2);
-    else
-        concat_up_kernel<float, NEAREST><<<grid, 256, 0, (hipStream_t)stream>>>((const float*)skip, (const float*)x, (float*)y, b, h, w, c1, c2);
+    ADVS_SWITCH_T(dtype, concat_up_kernel<T, NEAREST><<<grid, 256, 0, (hipStream_t)stream>>>((const T*)skip, (const T*)x, (T*)y, b, h, w, c1, c2));
     ADVS_CHECK_LAUNCH(name);
     return ADVS_OK;
 }
@@ -166,14 +162,11 @@ layernorm_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const
 extern "C" int advs_layernorm(const void* x, const float* gamma, const float* beta, void* y, long long rows, int c,
                               float eps, int dtype, void* stream) {
     ADVS_REQUIRE(x && gamma && beta && y && rows > 0 && c > 0, "layernorm: bad args");
-    const int vec = dtype == ADVS_BF16 ? 8 : 4;
+    const int vec = dtype == ADVS_F32 ? 4 : 8;
     ADVS_REQUIRE(c % vec == 0, "layernorm: c=%d must be a multiple of %d", c, vec);
     long long blocks = (rows + 15) / 16;
     const int grid = (int)(blocks < 8192 ? blocks : 8192);
-    if (dtype == ADVS_BF16)
-        layernorm_kernel<BF16><<<grid, 256, 0, (hipStream_t)stream>>>((const BF16*)x, gamma, beta, (BF16*)y, rows, c, eps);
-    else
-        layernorm_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>((const float*)x, gamma, beta, (float*)y, rows, c, eps);
+    ADVS_SWITCH_T(dtype, layernorm_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T*)x, gamma, beta, (T*)y, rows, c, eps));
     ADVS_CHECK_LAUNCH("layernorm");
     return ADVS_OK;
 }

@@ -65,12 +65,7 @@ extern "C" int advs_conv_stem(const float* x_nchw, const float* w_oihw, const fl
     const int ho = (h + 2 * pad - ksize) / stride + 1, wo = (w + 2 * pad - ksize) / stride + 1;
     const long long npix = (long long)b * ho * wo;
     const int grid = (int)((npix + 63) / 64 < 8192 ? (npix + 63) / 64 : 8192);
-    if (dtype == ADVS_BF16)
-        conv_stem_kernel<BF16><<<grid, 256, lds, (hipStream_t)stream>>>(x_nchw, w_oihw, bias, (BF16*)y, b, cin, h, w, cout,
-                                                                        ksize, stride, pad, ho, wo, act);
-    else
-        conv_stem_kernel<float><<<grid, 256, lds, (hipStream_t)stream>>>(x_nchw, w_oihw, bias, (float*)y, b, cin, h, w, cout,
-                                                                         ksize, stride, pad, ho, wo, act);
+    ADVS_SWITCH_T(dtype, conv_stem_kernel<T><<<grid, 256, lds, (hipStream_t)stream>>>(x_nchw, w_oihw, bias, (T*)y, b, cin, h, w, cout, ksize, stride, pad, ho, wo, act));
     ADVS_CHECK_LAUNCH("conv_stem");
     return ADVS_OK;
 }
@@ -110,13 +105,12 @@ __global__ void maxpool3s2_kernel(const T* __restrict__ x, T* __restrict__ y, in
 
 extern "C" int advs_maxpool3x3s2(const void* x, void* y, int b, int h, int w, int c, int dtype, void* stream) {
     ADVS_REQUIRE(x && y && b > 0 && h > 0 && w > 0, "maxpool3x3s2: bad args");
-    const int vec = dtype == ADVS_BF16 ? 8 : 4;
+    const int vec = dtype == ADVS_F32 ? 4 : 8;
     ADVS_REQUIRE(c % vec == 0, "maxpool3x3s2: c=%d must be a multiple of %d", c, vec);
     const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
     const size_t total = (size_t)b * ho * wo * (c / vec);
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    if (dtype == ADVS_BF16) maxpool3s2_kernel<BF16><<<grid, 256, 0, (hipStream_t)stream>>>((const BF16*)x, (BF16*)y, b, h, w, c, ho, wo);
-    else maxpool3s2_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>((const float*)x, (float*)y, b, h, w, c, ho, wo);
+    ADVS_SWITCH_T(dtype, maxpool3s2_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T*)x, (T*)y, b, h, w, c, ho, wo));
     ADVS_CHECK_LAUNCH("maxpool3x3s2");
     return ADVS_OK;
 }
@@ -139,8 +133,7 @@ global_avgpool_kernel(const T* __restrict__ x, float* __restrict__ y, int HW, in
 extern "C" int advs_global_avgpool(const void* x, float* y, int b, int hw, int c, int dtype, void* stream) {
     ADVS_REQUIRE(x && y && b > 0 && hw > 0 && c > 0, "global_avgpool: bad args");
     dim3 grid(cdiv(c, 64), b);
-    if (dtype == ADVS_BF16) global_avgpool_kernel<BF16><<<grid, 256, 0, (hipStream_t)stream>>>((const BF16*)x, y, hw, c);
-    else global_avgpool_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>((const float*)x, y, hw, c);
+    ADVS_SWITCH_T(dtype, global_avgpool_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T*)x, y, hw, c));
     ADVS_CHECK_LAUNCH("global_avgpool");
     return ADVS_OK;
 }
@@ -167,8 +160,7 @@ extern "C" int advs_patchify(const float* x_nchw, void* y, int b, int cin, int h
     ADVS_REQUIRE(x_nchw && y && b > 0 && cin > 0 && patch > 0 && h % patch == 0 && w % patch == 0, "patchify: bad args");
     const size_t total = (size_t)b * cin * h * w;
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    if (dtype == ADVS_BF16) patchify_kernel<BF16><<<grid, 256, 0, (hipStream_t)stream>>>(x_nchw, (BF16*)y, b, cin, h, w, patch);
-    else patchify_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>(x_nchw, (float*)y, b, cin, h, w, patch);
+    ADVS_SWITCH_T(dtype, patchify_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>(x_nchw, (T*)y, b, cin, h, w, patch));
     ADVS_CHECK_LAUNCH("patchify");
     return ADVS_OK;
 }
@@ -195,8 +187,7 @@ extern "C" int advs_vit_assemble(const void* patches, const float* cls, const fl
     ADVS_REQUIRE(patches && cls && pos && tokens && b > 0 && np > 0 && n_pad > np && c > 0, "vit_assemble: bad args");
     const size_t total = (size_t)b * n_pad * c;
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    if (dtype == ADVS_BF16) vit_assemble_kernel<BF16><<<grid, 256, 0, (hipStream_t)stream>>>((const BF16*)patches, cls, pos, (BF16*)tokens, b, np, n_pad, c);
-    else vit_assemble_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>((const float*)patches, cls, pos, (float*)tokens, b, np, n_pad, c);
+    ADVS_SWITCH_T(dtype, vit_assemble_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T*)patches, cls, pos, (T*)tokens, b, np, n_pad, c));
     ADVS_CHECK_LAUNCH("vit_assemble");
     return ADVS_OK;
 }
@@ -211,8 +202,7 @@ __global__ void gather_rows_kernel(const T* __restrict__ x, float* __restrict__ 
 }
 extern "C" int advs_gather_rows_f32(const void* x, float* y, int b, long long row_stride, int c, int dtype, void* stream) {
     ADVS_REQUIRE(x && y && b > 0 && c > 0 && row_stride > 0, "gather_rows_f32: bad args");
-    if (dtype == ADVS_BF16) gather_rows_kernel<BF16><<<cdiv((long long)b * c, 256), 256, 0, (hipStream_t)stream>>>((const BF16*)x, y, b, row_stride, c);
-    else gather_rows_kernel<float><<<cdiv((long long)b * c, 256), 256, 0, (hipStream_t)stream>>>((const float*)x, y, b, row_stride, c);
+    ADVS_SWITCH_T(dtype, gather_rows_kernel<T><<<cdiv((long long)b * c, 256), 256, 0, (hipStream_t)stream>>>((const T*)x, y, b, row_stride, c));
     ADVS_CHECK_LAUNCH("gather_rows_f32");
     return ADVS_OK;
 }

@@ -11,11 +11,11 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import ACT, BF16, F32, GN_RESIDUAL_AFTER_ACT, ConvArgs, check
+from ._lib import ACT, BF16, F16, F32, GN_RESIDUAL_AFTER_ACT, ConvArgs, check
 
-TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16}
-ESZ = {F32: 4, BF16: 2}
-SLAB_ELEMS = {F32: 32, BF16: 64}       # conv K-slab: 128 bytes of channels
+TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
+ESZ = {F32: 4, BF16: 2, F16: 2}
+SLAB_ELEMS = {F32: 32, BF16: 64, F16: 64}       # conv K-slab: 128 bytes of channels
 
 
 def dtype_code(name):
@@ -23,7 +23,9 @@ def dtype_code(name):
         return F32
     if name in (BF16, "bf16", "bfloat16", torch.bfloat16):
         return BF16
-    raise ValueError(f"unsupported compute dtype {name!r} (use 'fp32' or 'bf16')")
+    if name in (F16, "fp16", "f16", "float16", "half", torch.float16):
+        return F16
+    raise ValueError(f"unsupported compute dtype {name!r} (use 'fp32', 'bf16' or 'fp16')")
 
 
 def ptr(t):

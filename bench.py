@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
-PEAK_MFMA_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}     # MI355X_MICROARCH.md: dense peaks
+PEAK_MFMA_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}     # MI355X_MICROARCH.md: dense peaks
 
 
 def conv_profile(eng, reps=2):
@@ -64,7 +64,7 @@ def conv_profile(eng, reps=2):
                 # the fused shortcut (extra 1x1 operand) is the reference's separate Conv2d (diff_model.py:89,103)
                 k_total = a.ksize * a.ksize * (a.c1 + a.c2) + a.ce1 + a.ce2
                 t[2] += 2.0 * a.b * ho * wo * a.cout * k_total
-                esz = 2 if a.dtype == 1 else 4
+                esz = 4 if a.dtype == 0 else 2
                 t[3] += esz * (a.b * a.h * a.w_ * (a.c1 + a.c2) + a.cout * k_total
                                + a.b * ho * wo * (a.cout * (2 if a.residual else 1) + a.ce1 + a.ce2))
     for e in evs:
@@ -146,7 +146,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--ddim-steps", type=int, default=50)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()

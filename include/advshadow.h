@@ -8,7 +8,7 @@
  * replaces (paths relative to the reference tree).  Conventions:
  *   - plain pointers and sizes only; all tensor pointers are DEVICE pointers owned by the
  *     caller (e.g. torch tensors' data_ptr()); the library owns nothing but a 4 KiB zero page;
- *   - activations are NHWC ("channels last": [B][H][W][C]); dtype ADVS_F32 or ADVS_BF16;
+ *   - activations are NHWC ("channels last": [B][H][W][C]); dtype ADVS_F32, ADVS_BF16 or ADVS_F16;
  *   - every call enqueues on the given hipStream_t (passed as void*), never synchronises,
  *     allocates nothing, and is therefore legal inside stream capture;
  *   - return 0 on success, a negative ADVS_ERR_* otherwise; advs_last_error() has the text.
@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 enum { ADVS_OK = 0, ADVS_ERR_ARG = -1, ADVS_ERR_HIP = -2, ADVS_ERR_STATE = -3 };
-enum { ADVS_F32 = 0, ADVS_BF16 = 1 };
+enum { ADVS_F32 = 0, ADVS_BF16 = 1, ADVS_F16 = 2 };   /* 16-bit modes: 16-bit storage + MFMA, f32 accumulation */
 enum { ADVS_ACT_NONE = 0, ADVS_ACT_RELU = 1, ADVS_ACT_SILU = 2, ADVS_ACT_GELU = 3,
        ADVS_ACT_RELU6 = 4, ADVS_ACT_LRELU01 = 5, ADVS_ACT_LRELU001 = 6 };
 /* OR-ed into advs_groupnorm*'s `act`: y = act(norm(x)) + chan_add + residual instead of

@@ -34,3 +34,12 @@ class OneOp:
 
 def bf16_round(x):
     return x.to(torch.bfloat16).float()
+
+
+def tdt(dt):
+    return {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[dt]
+
+
+def lp_round(dt, x):
+    """x rounded to the storage type of compute mode dt (identity for fp32)."""
+    return x if dt == "fp32" else x.to(tdt(dt)).float()

@@ -1,6 +1,6 @@
 """Per-kernel parity on the MI355X: every C-ABI op against the same op restated with torch CPU
 fp32 functional calls (the op-level oracle).  f32 mode must agree to fp32 rounding
-noise; bf16 mode is compared with the reference evaluated on bf16-rounded operands."""
+noise; the 16-bit modes (bf16, fp16) are compared with the reference evaluated on operands rounded to that type."""
 import math
 
 import numpy as np
@@ -10,11 +10,11 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-from gpu_helpers import OneOp, bf16_round, dev, nchw, nhwc  # noqa: E402
+from gpu_helpers import OneOp, bf16_round, dev, lp_round, nchw, nhwc, tdt  # noqa: E402
 from advshadow_amd import _lib  # noqa: E402
 from advshadow_amd.engine import pack_conv_weight, dtype_code, ptr  # noqa: E402
 
-DTS = ["fp32", "bf16"]
+DTS = ["fp32", "bf16", "fp16"]
 
 
 def tol(dt, f32, bf16):
@@ -58,8 +58,8 @@ def test_conv2d(case, dt, tile):
     bias = rnd(Cout, seed=4) if has_b else None
     temb = rnd(B, Cout + 5, seed=5) if has_t else None          # strided rows
     xin = x1 if x2 is None else torch.cat([x1, x2], 1)
-    if dt == "bf16":
-        xin, wr = bf16_round(xin), bf16_round(w)
+    if dt != "fp32":
+        xin, wr = lp_round(dt, xin), lp_round(dt, w)
     else:
         wr = w
     if ups:
@@ -69,7 +69,7 @@ def test_conv2d(case, dt, tile):
     if has_t:
         ref = ref + temb[:, :Cout, None, None]
     if has_r:
-        ref = ref + (bf16_round(res) if dt == "bf16" else res)
+        ref = ref + (lp_round(dt, res) if dt != "fp32" else res)
     if act == "relu":
         ref = F.relu(ref)
     elif act == "silu":
@@ -95,13 +95,13 @@ def test_pack_conv_weight(dt):
     w = rnd(6, 5, 3, 3, seed=9)
     p = pack_conv_weight(w.to(dev()), dtype_code(dt)).float().cpu()
     ref = w.permute(0, 2, 3, 1)
-    ref = bf16_round(ref) if dt == "bf16" else ref
-    slab = 64 if dt == "bf16" else 32                      # input channels are zero-padded to whole 128-byte slabs
+    ref = lp_round(dt, ref) if dt != "fp32" else ref
+    slab = 64 if dt != "fp32" else 32                      # input channels are zero-padded to whole 128-byte slabs
     assert p.shape == (6, 3, 3, slab)
     assert torch.equal(p[..., :5], ref.contiguous()) and not p[..., 5:].any()
     w2 = rnd(4, 2 * slab, 1, 1, seed=10)
     p2 = pack_conv_weight(w2.to(dev()), dtype_code(dt)).float().cpu()
-    assert torch.equal(p2, (bf16_round(w2) if dt == "bf16" else w2).permute(0, 2, 3, 1).contiguous())
+    assert torch.equal(p2, (lp_round(dt, w2) if dt != "fp32" else w2).permute(0, 2, 3, 1).contiguous())
 
 
 @pytest.mark.parametrize("dt", DTS)
@@ -122,7 +122,7 @@ def test_conv_first(shape, dt):
 def test_conv_last(shape, dt):
     B, Cin, H, W, Cout, k = shape
     x, w, b = rnd(B, Cin, H, W, seed=1), rnd(Cout, Cin, k, k, seed=2, scale=0.1), rnd(Cout, seed=3)
-    xr = bf16_round(x) if dt == "bf16" else x
+    xr = lp_round(dt, x) if dt != "fp32" else x
     ref = F.conv2d(xr, w, b, padding=k // 2)
     op = OneOp(dt, B)
     out = torch.empty(B, Cout, H, W, device=dev())
@@ -155,11 +155,11 @@ def test_groupnorm(case, dt):
     gamma, beta = rnd(C, seed=3) * 0.5 + 1, rnd(C, seed=4) * 0.2
     res = rnd(B, C, H, W, seed=5) if has_r else None
     xin = x1 if x2 is None else torch.cat([x1, x2], 1)
-    if dt == "bf16":
-        xin = bf16_round(xin)
+    if dt != "fp32":
+        xin = lp_round(dt, xin)
     ref = F.group_norm(xin, G, gamma, beta, eps=1e-5)
     if has_r:
-        ref = ref + (bf16_round(res) if dt == "bf16" else res)
+        ref = ref + (lp_round(dt, res) if dt != "fp32" else res)
     ref = {"silu": F.silu, "gelu": F.gelu, None: lambda v: v}[act](ref)
     op = OneOp(dt, B)
     y = op.b.groupnorm(nhwc(x1, dt), gamma.to(dev()), beta.to(dev()), G, act=act,
@@ -196,8 +196,8 @@ def test_attention(case, dt):
     B, N, heads, d, lay = case
     C = heads * d
     qkv = rnd(B, N, 3 * C, seed=11)
-    if dt == "bf16":
-        qkv = bf16_round(qkv)
+    if dt != "fp32":
+        qkv = lp_round(dt, qkv)
     if lay == "b":      # per head [q|k|v] interleave (diff_model.py:120)
         t = qkv.view(B, N, heads, 3, d)
         q, k, v = t[:, :, :, 0], t[:, :, :, 1], t[:, :, :, 2]
@@ -211,7 +211,7 @@ def test_attention(case, dt):
     ref = (w @ v).permute(0, 2, 1, 3).reshape(B, N, C)
     op = OneOp(dt, B)
     side = int(math.isqrt(N))
-    x = qkv.view(B, side, side, 3 * C).to(dev(), torch.bfloat16 if dt == "bf16" else torch.float32)
+    x = qkv.view(B, side, side, 3 * C).to(dev(), tdt(dt))
     y = op.b.attention(x, heads, d, *offs)
     op.go()
     got = y.float().cpu().view(B, N, C)
@@ -292,12 +292,12 @@ def test_layout_roundtrip(dt):
     s = torch.cuda.current_stream().cuda_stream
     x = rnd(2, 37, 9, 11, seed=3)
     xd = x.to(dev())
-    y = torch.empty(2, 9, 11, 37, dtype=torch.bfloat16 if dt == "bf16" else torch.float32, device=dev())
+    y = torch.empty(2, 9, 11, 37, dtype=tdt(dt), device=dev())
     z = torch.empty_like(xd)
     code = dtype_code(dt)
     _lib.check(lib.advs_nchw_f32_to_nhwc(xd.data_ptr(), y.data_ptr(), 2, 37, 9, 11, code, s))
     _lib.check(lib.advs_nhwc_to_nchw_f32(y.data_ptr(), z.data_ptr(), 2, 37, 9, 11, code, s))
-    ref = bf16_round(x) if dt == "bf16" else x
+    ref = lp_round(dt, x) if dt != "fp32" else x
     assert torch.equal(y.float().cpu(), ref.permute(0, 2, 3, 1).contiguous())
     assert torch.equal(z.cpu(), ref)
 
@@ -306,7 +306,7 @@ def test_layout_roundtrip(dt):
 @pytest.mark.parametrize("dt", DTS)
 def test_maxpool2(dt):
     x = rnd(2, 64, 12, 16, seed=21)
-    xr = bf16_round(x) if dt == "bf16" else x
+    xr = lp_round(dt, x) if dt != "fp32" else x
     op = OneOp(dt, 2)
     y = op.b.maxpool2(nhwc(x, dt))
     op.go()
@@ -318,8 +318,8 @@ def test_maxpool2(dt):
 def test_concat_upsample2x(shape, dt):
     B, h, w, C1, C2 = shape
     skip, x = rnd(B, C1, 2 * h, 2 * w, seed=22), rnd(B, C2, h, w, seed=23)
-    if dt == "bf16":
-        skip, x = bf16_round(skip), bf16_round(x)
+    if dt != "fp32":
+        skip, x = lp_round(dt, skip), lp_round(dt, x)
     ref = torch.cat([skip, F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)], 1)
     op = OneOp(dt, B)
     y = op.b.concat_upsample2x(nhwc(skip, dt), nhwc(x, dt))
@@ -334,10 +334,10 @@ def test_layernorm(shape, dt):
     B, H, W, Cc = shape
     x = rnd(B, H, W, Cc, seed=24) * 3 + 1
     g, b = rnd(Cc, seed=25) + 1, rnd(Cc, seed=26)
-    xr = bf16_round(x) if dt == "bf16" else x
+    xr = lp_round(dt, x) if dt != "fp32" else x
     ref = F.layer_norm(xr, (Cc,), g, b, eps=1e-5)
     op = OneOp(dt, B)
-    y = op.b.layernorm(x.to(dev(), torch.bfloat16 if dt == "bf16" else torch.float32), g.to(dev()), b.to(dev()))
+    y = op.b.layernorm(x.to(dev(), tdt(dt)), g.to(dev()), b.to(dev()))
     op.go()
     err = (y.float().cpu() - ref).abs().max().item()
     assert err < tol(dt, 1e-5, 4e-2), err
@@ -348,7 +348,7 @@ def test_groupnorm_chan_add(dt):
     B, C, H, W = 2, 128, 8, 8
     x, emb = rnd(B, C, H, W, seed=27), rnd(B, C + 64, seed=28)
     g, b = rnd(C, seed=29) + 1, rnd(C, seed=30)
-    xr = bf16_round(x) if dt == "bf16" else x
+    xr = lp_round(dt, x) if dt != "fp32" else x
     ref = F.group_norm(xr, 1, g, b, eps=1e-5) + emb[:, 32:32 + C, None, None]
     op = OneOp(dt, B)
     e = emb.to(dev())
@@ -368,7 +368,7 @@ def test_groupnorm_with_epilogue_stats(dt, tiles):
     xa, xb = rnd(B, 64, H, W, seed=41), rnd(B, 64, H, W, seed=42)
     wa, wb = rnd(256, 64, 3, 3, seed=43, scale=0.05), rnd(128, 64, 1, 1, seed=44, scale=0.2)
     gamma, beta = rnd(384, seed=45) * 0.3 + 1, rnd(384, seed=46) * 0.1
-    r = (lambda t: bf16_round(t)) if dt == "bf16" else (lambda t: t)
+    r = (lambda t: lp_round(dt, t)) if dt != "fp32" else (lambda t: t)
     ya = r(F.conv2d(r(xa), r(wa), padding=1))
     yb = r(F.relu(F.conv2d(r(xb), r(wb))))
     ref = F.silu(F.group_norm(torch.cat([ya, yb], 1), 32, gamma, beta, eps=1e-5))
@@ -396,7 +396,7 @@ def test_conv2d_with_extra_1x1_operand(dt, tile, two):
     w3 = rnd(Cout, Ca, 3, 3, seed=54, scale=1 / math.sqrt(9 * Ca))
     w1 = rnd(Cout, E1 + E2, 1, 1, seed=55, scale=1 / math.sqrt(E1 + E2))
     bias = rnd(Cout, seed=56)
-    r = (lambda t: bf16_round(t)) if dt == "bf16" else (lambda t: t)
+    r = (lambda t: lp_round(dt, t)) if dt != "fp32" else (lambda t: t)
     e = e1 if e2 is None else torch.cat([e1, e2], 1)
     ref = F.conv2d(r(a), r(w3), bias, padding=1) + F.conv2d(r(e), r(w1))
     code = dtype_code(dt)
@@ -440,8 +440,8 @@ def test_attention_short_sequences_and_narrow_heads(case, dt):
     B, N, heads, d, lay = case
     C = heads * d
     qkv = rnd(B, N, 3 * C, seed=64)
-    if dt == "bf16":
-        qkv = bf16_round(qkv)
+    if dt != "fp32":
+        qkv = lp_round(dt, qkv)
     if lay == "b":
         t = qkv.view(B, N, heads, 3, d)
         q, k, v = t[:, :, :, 0], t[:, :, :, 1], t[:, :, :, 2]
@@ -453,7 +453,7 @@ def test_attention_short_sequences_and_narrow_heads(case, dt):
     q, k, v = (u.permute(0, 2, 1, 3) for u in (q, k, v))
     ref = (torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(d), dim=-1) @ v).permute(0, 2, 1, 3).reshape(B, N, C)
     op = OneOp(dt, B)
-    x = qkv.view(B, 1, N, 3 * C).to(dev(), torch.bfloat16 if dt == "bf16" else torch.float32)
+    x = qkv.view(B, 1, N, 3 * C).to(dev(), tdt(dt))
     y = op.b.attention(x, heads, d, *offs)
     op.go()
     err = (y.float().cpu().view(B, N, C) - ref).abs().max().item()
@@ -465,8 +465,8 @@ def test_attention_short_sequences_and_narrow_heads(case, dt):
 def test_concat_nearest2x(shape, dt):
     B, h, w, C1, C2 = shape
     skip, x = rnd(B, C1, 2 * h, 2 * w, seed=65), rnd(B, C2, h, w, seed=66)
-    if dt == "bf16":
-        skip, x = bf16_round(skip), bf16_round(x)
+    if dt != "fp32":
+        skip, x = lp_round(dt, skip), lp_round(dt, x)
     ref = torch.cat([skip, F.interpolate(x, scale_factor=2, mode="nearest")], 1)
     op = OneOp(dt, B)
     y = op.b.concat_nearest2x(nhwc(skip, dt), nhwc(x, dt))
@@ -480,7 +480,7 @@ def test_groupnorm_residual_after_activation(dt):
     B, C, H, W = 2, 64, 8, 8
     x, r, emb = rnd(B, C, H, W, seed=67), rnd(B, C, H, W, seed=68), rnd(B, C, seed=69)
     g, b = rnd(C, seed=70) + 1, rnd(C, seed=71)
-    xr, rr = (bf16_round(x), bf16_round(r)) if dt == "bf16" else (x, r)
+    xr, rr = (lp_round(dt, x), lp_round(dt, r)) if dt != "fp32" else (x, r)
     ref = F.silu(F.group_norm(xr, 1, g, b, eps=1e-5)) + emb[:, :, None, None] + rr
     op = OneOp(dt, B)
     e = emb.to(dev())
