@@ -62,6 +62,7 @@ SIGNATURES = {
     "advs_u8hwc_to_f32nchw": [vp, vp, i32, i32, i32, i32, vp, vp, vp],
     "advs_u8_nchw_to_hwc": [vp, vp, i32, i32, i32, i32, vp],
     "advs_psnr_ssim": [vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "advs_jpeg_roundtrip_u8": [vp, vp, vp, i32, i32, i32, i32, vp],
     "advs_argmax_rows": [vp, vp, i32, i32, vp],
     "advs_conv_stem": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "advs_maxpool3x3s2": [vp, vp, i32, i32, i32, i32, i32, vp],
@@ -76,8 +77,8 @@ SIGNATURES = {
     "advs_event_destroy": [vp],
     "advs_stream_sync": [vp],
 }
-_RESTYPES = {"advs_last_error": C.c_char_p, "advs_groupnorm_scratch_bytes": sz}
-_EXTRA = {"advs_last_error": [], "advs_groupnorm_scratch_bytes": [i32, i32]}
+_RESTYPES = {"advs_last_error": C.c_char_p, "advs_groupnorm_scratch_bytes": sz, "advs_jpeg_scratch_bytes": sz}
+_EXTRA = {"advs_last_error": [], "advs_groupnorm_scratch_bytes": [i32, i32], "advs_jpeg_scratch_bytes": [i32, i32, i32]}
 
 _lib = None
 

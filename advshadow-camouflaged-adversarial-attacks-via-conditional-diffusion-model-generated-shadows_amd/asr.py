@@ -38,9 +38,10 @@ def _logits(model, x):
     return out.logits if hasattr(out, "logits") else out        # HF models (ASR_fast.py:114, commented)
 
 
-def evaluate_batch(images_u8_nchw, model, size=224, mean=None, std=None):
-    """uint8 [n,3,S,S] (GPU) -> int32 [n] predicted class indices."""
-    x = preprocess_batch(images_u8_nchw, size, mean, std)
+def evaluate_batch(images_u8_nchw, model, size=224, mean=None, std=None, jpeg_quality=None):
+    """uint8 [n,3,S,S] (GPU) -> int32 [n] predicted class indices.  ``jpeg_quality=75`` reproduces the ``.jpg``
+    files the reference's generate() writes and ASR_fast.py reads back (bit-exact pixels, no file)."""
+    x = preprocess_batch(images_u8_nchw, size, mean, std, jpeg_quality)
     return argmax_rows(_logits(model, x))
 
 

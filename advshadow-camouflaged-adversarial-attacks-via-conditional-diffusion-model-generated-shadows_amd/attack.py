@@ -31,10 +31,11 @@ def to_64(images_f32_nchw):
 
 
 def attack_shard(sample_fn, victim, clean, feature_masks, centers, radii, shadow_intensity=0.43, blur_kernel_size=5,
-                 win_size=7):
+                 win_size=7, jpeg_quality=None):
     """One shard: returns (generated uint8 [n,3,S,S], pred int32 [n], psnr f32 [n], ssim f32 [n])."""
     generated = sample_fn()                                           # DDIM sampler output, uint8 on the GPU
-    pred = evaluate_batch(generated, victim)                          # resize 224 -> victim -> argmax
+    # [.jpg round trip, as generate()'s default image_format implies ->] resize 224 -> victim -> argmax
+    pred = evaluate_batch(generated, victim, jpeg_quality=jpeg_quality)
     shadowed = apply_shadow_batch(clean, centers, radii, feature_masks, shadow_intensity, blur_kernel_size)
     sp = ssim_psnr_batch(to_64(clean), to_64(shadowed), win_size)     # [n,2] f64 (ssim, psnr)
     return generated, pred, sp[:, 1].float(), sp[:, 0].float()

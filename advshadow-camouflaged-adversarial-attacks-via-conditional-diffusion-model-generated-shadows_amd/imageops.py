@@ -101,9 +101,32 @@ def to_tensor(images_hwc, mean=None, std=None, stream=None):
     return out
 
 
-def preprocess_batch(images_u8_nchw, size=224, mean=None, std=None):
+def jpeg_roundtrip(images_hwc, quality=75, stream=None):
+    """What ``Image.save(path.jpg)`` + ``Image.open(path)`` does to the pixels (utils/utils.py:51-91 ->
+    ASR_fast.py:90-92), without the file: uint8 [n,H,W,3] -> uint8 [n,H,W,3], bit-exact with Pillow's baseline
+    4:2:0 round trip at ``quality`` (Pillow's default 75).  H and W must be multiples of 16."""
+    _lib.init_device()
+    lib = _lib.load()
+    n, H, W, ch = images_hwc.shape
+    if ch != 3:
+        raise ValueError("jpeg_roundtrip expects RGB images [n,H,W,3]")
+    dev = images_hwc.device
+    x = images_hwc.contiguous()
+    out = torch.empty_like(x)
+    scratch = torch.empty(lib.advs_jpeg_scratch_bytes(n, H, W), dtype=torch.uint8, device=dev)
+    s = (stream or torch.cuda.current_stream(dev)).cuda_stream
+    check(lib.advs_jpeg_roundtrip_u8(x.data_ptr(), out.data_ptr(), scratch.data_ptr(), n, H, W, int(quality), s),
+          "jpeg_roundtrip_u8")
+    scratch.record_stream(torch.cuda.current_stream(dev) if stream is None else stream)
+    return out
+
+
+def preprocess_batch(images_u8_nchw, size=224, mean=None, std=None, jpeg_quality=None):
     """The batched, on-device form of ``preprocess_image`` (ASR_fast.py:90-97): uint8 [n,3,S,S]
     sampler output -> Resize((size,size)) -> ToTensor -> f32 [n,3,size,size] (no normalisation
-    unless mean/std are given, as test.py:118-122 does)."""
+    unless mean/std are given, as test.py:118-122 does).  ``jpeg_quality`` (e.g. 75) inserts the lossy
+    ``.jpg`` hop the reference's scripts put between the sampler and the victim."""
     hwc = u8_nchw_to_hwc(images_u8_nchw)
+    if jpeg_quality is not None:
+        hwc = jpeg_roundtrip(hwc, jpeg_quality)
     return to_tensor(resize_u8(hwc, size, size), mean, std)

@@ -212,6 +212,16 @@ int advs_u8hwc_to_f32nchw(const uint8_t* in, float* out, int n, int h, int w, in
                           const float* mean, const float* stdv, void* stream);
 /* uint8 [n][ch][h][w] -> [n][h][w][ch]: the permute of save_images (utils/utils.py:59-60).           */
 int advs_u8_nchw_to_hwc(const uint8_t* in, uint8_t* out, int n, int channels, int h, int w, void* stream);
+/* ---- the JPEG file hop, on the device ---------------------------------------------------
+ * What saving an image as .jpg and reading it back does to its pixels (utils/utils.py:51-91 Image.save
+ * with Pillow's defaults -> ASR_fast.py:90-92 / PSNR_SSIM_fast.py:21-24 Image.open): baseline JPEG, 4:2:0,
+ * integer colour conversion, "islow" DCTs, quantisation at `quality` (Pillow's default 75), triangle chroma
+ * upsampling.  Bit-exact with Pillow's round trip.  src/dst: uint8 [n][h][w][3]; h, w multiples of 16;
+ * scratch: advs_jpeg_scratch_bytes(n, h, w) bytes.                                                    */
+size_t advs_jpeg_scratch_bytes(int n, int h, int w);
+int advs_jpeg_roundtrip_u8(const unsigned char* src, unsigned char* dst, void* scratch, int n, int h, int w,
+                           int quality, void* stream);
+
 /* calculate_ssim_psnr (PSNR_SSIM_fast.py:21-26, skimage semantics) for b image pairs, NCHW f32,
  * planes <= 64x64: out[b] = {ssim, psnr} as f64.                                                 */
 int advs_psnr_ssim(const float* img1, const float* img2, double* out_ssim_psnr, int b, int c, int h, int w,

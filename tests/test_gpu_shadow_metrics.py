@@ -109,3 +109,63 @@ def test_argmax_and_asr():
     assert metrics.attack_success(pred, true) == 3 / 9
     names = [f"Abyssinian_{i}.jpg" for i in range(3)] + ["notes.txt"]
     assert om.compute_asr(names, ["Abyssinian", "Bengal", "Abyssinian", "x"]) == 1 / 3
+
+
+# ------------------------------------------------------------------------------ JPEG file hop on the device
+def _pil_jpeg(a, **kw):
+    import io
+    buf = io.BytesIO()
+    Image.fromarray(a).save(buf, "JPEG", **kw)
+    buf.seek(0)
+    return np.asarray(Image.open(buf).convert("RGB"))
+
+
+@pytest.mark.parametrize("quality", [None, 30, 75, 95, 100])
+def test_jpeg_roundtrip_bit_exact_vs_pillow_and_oracle(quality):
+    """advs_jpeg_roundtrip_u8 == Pillow's save(.jpg)/open == oracle/jpeg.py, bit for bit: noise, smooth ramps,
+    saturated colours, flat images, a rectangular batch."""
+    from oracle import jpeg as oj
+    rng = np.random.default_rng(11)
+    yy, xx = np.mgrid[0:64, 0:64]
+    smooth = np.stack([(yy * 4) % 256, (xx * 3 + yy) % 256, (255 - xx * 2) % 256], -1).astype(np.uint8)
+    batch = np.stack([smooth, rng.integers(0, 256, (64, 64, 3), dtype=np.uint8),
+                      (0.6 * smooth + 0.4 * rng.integers(0, 256, (64, 64, 3))).astype(np.uint8),
+                      np.zeros((64, 64, 3), np.uint8), np.full((64, 64, 3), 255, np.uint8),
+                      np.tile(np.array([[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 0, 255]], np.uint8).repeat(16, 0)[None], (64, 1, 1))])
+    kw = {} if quality is None else {"quality": quality}
+    got = imageops.jpeg_roundtrip(torch.from_numpy(batch).cuda(), **kw).cpu().numpy()
+    for i in range(batch.shape[0]):
+        assert np.array_equal(got[i], _pil_jpeg(batch[i], **kw)), i
+        assert np.array_equal(got[i], oj.jpeg_roundtrip(batch[i], quality or 75)), i
+    rect = rng.integers(0, 256, (2, 48, 160, 3), dtype=np.uint8)
+    got = imageops.jpeg_roundtrip(torch.from_numpy(rect).cuda(), **kw).cpu().numpy()
+    for i in range(2):
+        assert np.array_equal(got[i], _pil_jpeg(rect[i], **kw)), i
+
+
+def test_jpeg_roundtrip_full_size_and_errors():
+    """256x256 x 8 images against Pillow; sizes that are not whole MCUs are rejected."""
+    from advshadow_amd import _lib
+    rng = np.random.default_rng(12)
+    base = rng.integers(0, 256, (8, 32, 32, 3), dtype=np.uint8)
+    big = np.stack([np.asarray(Image.fromarray(b).resize((256, 256), Image.BICUBIC)) for b in base])     # photo-like content
+    got = imageops.jpeg_roundtrip(torch.from_numpy(big).cuda()).cpu().numpy()
+    for i in range(8):
+        assert np.array_equal(got[i], _pil_jpeg(big[i])), i
+    with pytest.raises(_lib.AdvsError):
+        imageops.jpeg_roundtrip(torch.zeros((1, 20, 32, 3), dtype=torch.uint8, device="cuda"))
+
+
+def test_preprocess_batch_with_jpeg_matches_the_file_pipeline(tmp_path):
+    """sampler uint8 -> save as .jpg (utils/utils.py) -> ASR_fast.preprocess_image, against the on-device path."""
+    rng = np.random.default_rng(13)
+    base = rng.integers(0, 256, (3, 16, 16, 3), dtype=np.uint8)
+    imgs = np.stack([np.asarray(Image.fromarray(b).resize((64, 64), Image.BICUBIC)) for b in base])
+    ref = []
+    for i in range(3):
+        p = tmp_path / f"x_{i}.jpg"
+        Image.fromarray(imgs[i]).save(p)
+        im = Image.open(p).convert("RGB").resize((224, 224), Image.BILINEAR)
+        ref.append(np.asarray(im, dtype=np.float32).transpose(2, 0, 1) / 255.0)
+    got = imageops.preprocess_batch(torch.from_numpy(imgs.transpose(0, 3, 1, 2).copy()).cuda(), 224, jpeg_quality=75).cpu().numpy()
+    assert np.array_equal(got, np.stack(ref))

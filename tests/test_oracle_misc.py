@@ -1,6 +1,7 @@
 """CPU checks of the oracle pieces that have something to be pinned against in this image:
 Pillow (the reference's own library) for resize coefficients, scipy for the SSIM window."""
 import numpy as np
+import pytest
 from PIL import Image
 
 from advshadow_amd.imageops import bilinear_coeffs
@@ -39,3 +40,36 @@ def test_ssim_identity_and_psnr_formula():
     b = np.clip(a + 0.1, 0, 1.1).astype(np.float32)
     R = float(a.max() - a.min())
     assert abs(om.peak_signal_noise_ratio(a, b, R) - 10 * np.log10(R * R / np.mean((a - b) ** 2, dtype=np.float64))) < 1e-9
+
+
+# ------------------------------------------------------------------------------ JPEG file hop
+def _pil_jpeg_roundtrip(a, **kw):
+    import io
+    from PIL import Image
+    buf = io.BytesIO()
+    Image.fromarray(a).save(buf, "JPEG", **kw)
+    buf.seek(0)
+    return np.asarray(Image.open(buf).convert("RGB"))
+
+
+def jpeg_cases():
+    rng = np.random.default_rng(5)
+    yy, xx = np.mgrid[0:64, 0:64]
+    smooth = np.stack([(yy * 4) % 256, (xx * 3 + yy) % 256, (255 - xx * 2) % 256], -1).astype(np.uint8)
+    noise = rng.integers(0, 256, (64, 64, 3), dtype=np.uint8)
+    return {"smooth": smooth, "noise": noise, "mix": (0.7 * smooth + 0.3 * noise).astype(np.uint8),
+            "rect": rng.integers(0, 256, (48, 128, 3), dtype=np.uint8), "black": np.zeros((32, 32, 3), np.uint8),
+            "white": np.full((32, 32, 3), 255, np.uint8),
+            "checker": ((np.indices((64, 64)).sum(0) % 2) * 255).astype(np.uint8)[..., None].repeat(3, 2)}
+
+
+def test_jpeg_roundtrip_oracle_is_pillow_exact():
+    """oracle/jpeg.py against Pillow's own save/open (Pillow defaults = what utils/utils.py:51-91 writes and
+    ASR_fast.py:90-92 reads): bit-exact, every quality."""
+    from oracle import jpeg as oj
+    for name, a in jpeg_cases().items():
+        assert np.array_equal(oj.jpeg_roundtrip(a), _pil_jpeg_roundtrip(a)), name             # default quality
+        for q in (30, 75, 90, 100):
+            assert np.array_equal(oj.jpeg_roundtrip(a, q), _pil_jpeg_roundtrip(a, quality=q)), (name, q)
+    with pytest.raises(ValueError):
+        oj.jpeg_roundtrip(np.zeros((20, 32, 3), np.uint8))
