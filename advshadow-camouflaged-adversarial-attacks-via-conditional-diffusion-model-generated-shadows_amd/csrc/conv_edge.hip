@@ -2,6 +2,7 @@
 // (K = 27 on the way in, N = 3 on the way out), so both are direct, HBM-bound kernels that
 // also perform the NCHW <-> NHWC change of layout at the model boundary.
 #include "common.h"
+#include <type_traits>
 
 // ---------------------------------------------------------------- first conv: NCHW f32 -> NHWC T
 // cout/8 consecutive lanes own a run of CF_PX consecutive output pixels of one row, 8 channels
@@ -108,7 +109,9 @@ conv_last_kernel(const T* __restrict__ x, const float* __restrict__ w, const flo
     const int vpp = Cin / VEC, pad = R / 2;
     const int runs_per_row = (W + CL_PX - 1) / CL_PX;
     const long long nruns = (long long)B * H * runs_per_row;
-    for (long long rb = (long long)blockIdx.x * 16; rb < nruns; rb += (long long)gridDim.x * 16) {
+    const int nb = gridDim.x, xq = nb >> 3, xr = nb & 7, xcd = blockIdx.x & 7;     // XCD-contiguous row bands (see below)
+    const int bid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
+    for (long long rb = (long long)bid * 16; rb < nruns; rb += (long long)nb * 16) {
         const long long run = rb + grp;
         const bool live = run < nruns;
         float acc[CL_PX][4];
@@ -165,6 +168,332 @@ conv_last_kernel(const T* __restrict__ x, const float* __restrict__ w, const flo
     }
 }
 
+// ---------------------------------------------------------------- last conv, 16-bit activations
+// Same contract, written around v_dot2c_f32_{bf16,f16}: the activations stay packed (no unpack), the
+// weights are rounded to T like every other conv's in the 16-bit modes and parked in LDS as channel pairs
+// ([tap][channel vector][output][4 x u32]).  16 lanes own a run of 8 output pixels of one row; per filter
+// row the run's 10 input vectors are loaded once and serve the three horizontal taps.  The 24 partial sums
+// (8 pixels x 3 outputs) are folded over the 16 lanes with a halving butterfly (24 shuffles instead of 96).
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+template <typename T> __device__ __forceinline__ float dot2acc(unsigned a, unsigned b, float c);
+template <> __device__ __forceinline__ float dot2acc<BF16>(unsigned a, unsigned b, float c) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
+}
+template <> __device__ __forceinline__ float dot2acc<F16>(unsigned a, unsigned b, float c) {
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, a), __builtin_bit_cast(f16x2_t, b), c, false);
+}
+
+template <typename T, int R>
+__global__ void __launch_bounds__(256)
+conv_last16_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                   float* __restrict__ y, int B, int Cin, int H, int W, int Cout, const u32x4* __restrict__ zero) {
+    constexpr int TAPS = R * R, PAD = R / 2, PXR = 8;
+    extern __shared__ u32x4 swq[];                // [tap][vpp][3]
+    const int vpp = Cin / 8;
+    for (int i = threadIdx.x; i < TAPS * vpp * 3; i += 256) {
+        const int o = i % 3, cv = (i / 3) % vpp, t = i / (3 * vpp);
+        u32x4 q;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = cv * 8 + 2 * j;
+            const float lo = o < Cout ? w[((size_t)o * Cin + c) * TAPS + t] : 0.f;
+            const float hi = o < Cout ? w[((size_t)o * Cin + c + 1) * TAPS + t] : 0.f;
+            q[j] = pack2<T>(lo, hi);
+        }
+        swq[i] = q;
+    }
+    __syncthreads();
+    const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int runs_per_row = (W + PXR - 1) / PXR;
+    const int nruns = B * H * runs_per_row;             // < 2^31, checked by the host
+    // Workgroups are dealt round-robin to the 8 XCDs.  Give each XCD a contiguous band of rows, so that the two
+    // neighbour rows every output row needs are found in that XCD's own L2 instead of being fetched by three XCDs.
+    const int nb = gridDim.x, xq = nb >> 3, xr = nb & 7, xcd = blockIdx.x & 7;
+    const int bid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
+    for (int rb = bid * 16; rb < nruns; rb += nb * 16) {
+        const int run = rb + grp;
+        const bool live = run < nruns;
+        float acc[PXR * 3];
+#pragma unroll
+        for (int i = 0; i < PXR * 3; ++i) acc[i] = 0.f;
+        int b = 0, oy = 0, ox0 = 0;
+        if (live) {
+            const int rowid = run / runs_per_row, rr = run - rowid * runs_per_row;
+            b = rowid / H; oy = rowid - b * H; ox0 = rr * PXR;
+            for (int cv = l16; cv < vpp; cv += 16) {
+#pragma unroll 1                                  // one filter row's inputs live at a time
+                for (int r = 0; r < R; ++r) {
+                    const int iy = oy + r - PAD;
+                    if ((unsigned)iy >= (unsigned)H) continue;
+                    const u32x4* rowp = (const u32x4*)(x + (((size_t)b * H + iy) * W) * Cin) + cv;
+                    int opaque = 0;                   // keeps the weight reads inside the loop: 12 live registers
+                    asm volatile("" : "+v"(opaque));  // instead of 108, i.e. 5 instead of 2 waves per SIMD
+                    u32x4 in[PXR + 2 * PAD];
+#pragma unroll
+                    for (int q = 0; q < PXR + 2 * PAD; ++q) {
+                        // unconditional load through a selected POINTER (zero page outside the row): a conditional
+                        // load becomes a branch with its own wait, which serialises the ten loads of the row
+                        const int ix = ox0 + q - PAD;
+                        in[q] = *((unsigned)ix < (unsigned)W ? rowp + (size_t)ix * vpp : zero);
+                    }
+#pragma unroll
+                    for (int sx = 0; sx < R; ++sx) {
+                        const u32x4* wq = swq + ((r * R + sx) * vpp + cv) * 3 + opaque;
+                        const u32x4 w0 = wq[0], w1 = wq[1], w2 = wq[2];
+#pragma unroll
+                        for (int p = 0; p < PXR; ++p)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                acc[p * 3] = dot2acc<T>(in[p + sx][j], w0[j], acc[p * 3]);
+                                acc[p * 3 + 1] = dot2acc<T>(in[p + sx][j], w1[j], acc[p * 3 + 1]);
+                                acc[p * 3 + 2] = dot2acc<T>(in[p + sx][j], w2[j], acc[p * 3 + 2]);
+                            }
+                    }
+                }
+            }
+        }
+        // halving butterfly: after the steps with lane bits 8, 4, 2 the lane holds the three outputs of pixel
+        // p = 4*bit3 + 2*bit2 + bit1 summed over its partners; the last step folds bit 0.
+#pragma unroll
+        for (int n = 12, m = 8; n >= 3; n >>= 1, m >>= 1) {
+            const bool upper = (l16 & m) != 0;
+#pragma unroll
+            for (int i = 0; i < n; ++i) {
+                const float send = upper ? acc[i] : acc[i + n];
+                const float keep = upper ? acc[i + n] : acc[i];
+                acc[i] = keep + __shfl_xor(send, m);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) acc[i] += __shfl_xor(acc[i], 1);
+        if (live && !(l16 & 1)) {
+            const int p = l16 >> 1, ox = ox0 + p;
+            if (ox < W)
+#pragma unroll
+                for (int o = 0; o < 3; ++o)
+                    if (o < Cout) y[(((size_t)b * Cout + o) * H + oy) * W + ox] = acc[o] + (bias ? bias[o] : 0.f);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- last conv on the matrix cores
+// v_mfma_f32_16x16x32: 16 pixels x 16 output columns (Cout <= 3 of them real) x 32 channels per instruction.
+// The A fragment of a lane -- pixel (lane & 15), 8 consecutive channels at 8 * (lane >> 4) -- is exactly one
+// 16-byte piece of the NHWC row, so activations go global -> registers -> MFMA with no LDS at all; the taps
+// re-read the shifted pixels through L1.  The B fragments (weights, TAPS x Cin/32 of them) are read from LDS
+// (36 KiB at Cin = 128; in registers they would cost 144 VGPRs and the occupancy that hides the load latency).  36 MFMAs of 16 cycles per 16 pixels replace ~860
+// multi-cycle dot2 instructions per 32.
+typedef __attribute__((ext_vector_type(8))) __bf16 mbf16x8;
+template <typename T> __device__ __forceinline__ f32x4 mma16x16(const u32x4& a, const u32x4& b, const f32x4& c);
+template <> __device__ __forceinline__ f32x4 mma16x16<BF16>(const u32x4& a, const u32x4& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mbf16x8, a), __builtin_bit_cast(mbf16x8, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x4 mma16x16<F16>(const u32x4& a, const u32x4& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+template <typename T, int R, int KS>
+__global__ void __launch_bounds__(256)
+conv_last_mfma_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                      float* __restrict__ y, int B, int H, int W, int Cout, const char* __restrict__ zero) {
+    constexpr int TAPS = R * R, PAD = R / 2, Cin = KS * 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    // B fragments (column n = an output channel, k = 8g .. 8g+7) parked in LDS as [tap][k-step][lane]
+    __shared__ u32x4 sbw[TAPS * KS * 64];
+    for (int i = threadIdx.x; i < TAPS * KS * 64; i += 256) {
+        const int l = i & 63, ks = (i >> 6) % KS, t = (i >> 6) / KS, nn = l & 15, gg = l >> 4;
+        u32x4 q;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = ks * 32 + gg * 8 + 2 * j;
+            const float lo = nn < Cout ? w[((size_t)nn * Cin + c) * TAPS + t] : 0.f;
+            const float hi = nn < Cout ? w[((size_t)nn * Cin + c + 1) * TAPS + t] : 0.f;
+            q[j] = pack2<T>(lo, hi);
+        }
+        sbw[i] = q;
+    }
+    __syncthreads();
+    const float bv = (bias && n < Cout) ? bias[n] : 0.f;
+    const int tiles_per_row = (W + 15) >> 4;
+    const int ntiles = B * H * tiles_per_row;       // < 2^31, checked by the host
+    // XCD-contiguous bands of rows (workgroups are dealt round-robin to the 8 XCDs)
+    const int nb = gridDim.x, xq = nb >> 3, xr = nb & 7, xcd = blockIdx.x & 7;
+    const int bid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
+    for (int tile = bid * 4 + wave; tile < ntiles; tile += nb * 4) {
+        const int rowid = tile / tiles_per_row, tx = tile - rowid * tiles_per_row;
+        const int b = rowid / H, oy = rowid - b * H, ox0 = tx * 16;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int iy = oy + r - PAD;
+            if ((unsigned)iy >= (unsigned)H) continue;               // wave-uniform: a tile lies in one row
+            const char* rowp = (const char*)(x + ((size_t)b * H + iy) * W * Cin) + g * 16;
+            u32x4 a[R][KS];
+#pragma unroll
+            for (int sx = 0; sx < R; ++sx) {
+                const int ix = ox0 + n + sx - PAD;
+                const char* p = (unsigned)ix < (unsigned)W ? rowp + (size_t)ix * (Cin * 2) : zero;
+                const int step = (unsigned)ix < (unsigned)W ? 64 : 0;  // the zero page is 128 bytes: do not walk off it
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) a[sx][ks] = *(const u32x4*)(p + ks * step);
+            }
+#pragma unroll
+            for (int sx = 0; sx < R; ++sx)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) acc = mma16x16<T>(a[sx][ks], sbw[((r * R + sx) * KS + ks) * 64 + lane], acc);
+        }
+        // D: lane holds column n, pixels 4g .. 4g+3 of the tile
+        if (n < Cout) {
+            float* yo = y + (((size_t)b * Cout + n) * H + oy) * W + ox0 + 4 * g;
+            if ((W & 3) == 0 && ox0 + 4 * g + 3 < W) {
+                *(f32x4*)yo = f32x4{acc[0] + bv, acc[1] + bv, acc[2] + bv, acc[3] + bv};
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (ox0 + 4 * g + i < W) yo[i] = acc[i] + bv;
+            }
+        }
+    }
+}
+
+// 3x3 variant that walks DOWN a 16-pixel-wide strip: every input row is loaded once (one centre fragment per
+// 32 channels plus the two edge pixels) and kept in registers for the three output rows that use it; the
+// horizontally shifted fragments of the left / right taps are made with DPP row shifts (pixel = lane & 15, so
+// a one-pixel shift is a one-lane shift inside the 16-lane row; the vacated lane takes the edge pixel).
+// 8 loads per 16 output pixels instead of 36, and HBM sees each row once.  Three row slots rotate.
+template <typename T, int KS>
+__global__ void __launch_bounds__(256, 2)
+conv_last_strip_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                       float* __restrict__ y, int B, int H, int W, int Cout, int RC, const char* __restrict__ zero) {
+    constexpr int TAPS = 9, Cin = KS * 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    __shared__ u32x4 sbw[TAPS * KS * 64];          // B fragments [tap][k-step][lane]: column n, k = 8g .. 8g+7
+    for (int i = threadIdx.x; i < TAPS * KS * 64; i += 256) {
+        const int l = i & 63, ks = (i >> 6) % KS, t = (i >> 6) / KS, nn = l & 15, gg = l >> 4;
+        u32x4 q;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = ks * 32 + gg * 8 + 2 * j;
+            const float lo = nn < Cout ? w[((size_t)nn * Cin + c) * TAPS + t] : 0.f;
+            const float hi = nn < Cout ? w[((size_t)nn * Cin + c + 1) * TAPS + t] : 0.f;
+            q[j] = pack2<T>(lo, hi);
+        }
+        sbw[i] = q;
+    }
+    __syncthreads();
+    const float bv = (bias && n < Cout) ? bias[n] : 0.f;
+    const int tiles_per_row = (W + 15) >> 4, chunks = (H + RC - 1) / RC;
+    const int nstrips = B * chunks * tiles_per_row;
+    const int nb = gridDim.x, xq = nb >> 3, xr = nb & 7, xcd = blockIdx.x & 7;     // XCD-contiguous bands
+    const int bid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
+    for (int strip = bid * 4 + wave; strip < nstrips; strip += nb * 4) {
+        const int bc = strip / tiles_per_row, tx = strip - bc * tiles_per_row;
+        const int b = bc / chunks, ch = bc - b * chunks;
+        const int y0 = ch * RC, y1 = min(H, y0 + RC), ox0 = tx * 16;
+        const int ixc = ox0 + n, ixe = n == 0 ? ox0 - 1 : ox0 + 16;       // centre pixel / edge pixel of this lane
+        const bool okc = ixc < W, oke = (unsigned)ixe < (unsigned)W;
+        const size_t offc = ((size_t)b * H * W + ixc) * (Cin * 2) + g * 16, offe = ((size_t)b * H * W + ixe) * (Cin * 2) + g * 16;
+        u32x4 c[3][KS], e[3][KS];
+        auto load_row = [&](auto slot, int iy) {
+            constexpr int sl = decltype(slot)::value;
+            const bool rowok = (unsigned)iy < (unsigned)H;
+            const char* rp = (const char*)x + (size_t)(rowok ? iy : 0) * W * (Cin * 2);
+            const char* pc = (rowok && okc) ? rp + offc : zero;
+            const char* pe = (rowok && oke) ? rp + offe : zero;
+            const int stc = (rowok && okc) ? 64 : 0, ste = (rowok && oke) ? 64 : 0;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) { c[sl][ks] = *(const u32x4*)(pc + ks * stc); e[sl][ks] = *(const u32x4*)(pe + ks * ste); }
+        };
+        auto row_mma = [&](auto slot, int r, f32x4& acc) {
+            constexpr int sl = decltype(slot)::value;
+            int opq = 0;                               // keeps the (loop-invariant) weight reads where they are:
+            asm volatile("" : "+v"(opq));              // hoisted out of the row loop they would pin 144 registers
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                u32x4 lft, rgt;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    lft[j] = (unsigned)__builtin_amdgcn_update_dpp((int)e[sl][ks][j], (int)c[sl][ks][j], 0x111, 0xf, 0xf, false);  // row_shr:1
+                    rgt[j] = (unsigned)__builtin_amdgcn_update_dpp((int)e[sl][ks][j], (int)c[sl][ks][j], 0x101, 0xf, 0xf, false);  // row_shl:1
+                }
+                const u32x4* bq = sbw + ((r * 3) * KS + ks) * 64 + lane + opq;
+                acc = mma16x16<T>(lft, bq[0], acc);
+                acc = mma16x16<T>(c[sl][ks], bq[KS * 64], acc);
+                acc = mma16x16<T>(rgt, bq[2 * KS * 64], acc);
+            }
+        };
+        auto out_row = [&](int oy, const f32x4& acc) {
+            if (n < Cout) {
+                float* yo = y + (((size_t)b * Cout + n) * H + oy) * W + ox0 + 4 * g;
+                if ((W & 3) == 0 && ox0 + 4 * g + 3 < W) {
+                    *(f32x4*)yo = f32x4{acc[0] + bv, acc[1] + bv, acc[2] + bv, acc[3] + bv};
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (ox0 + 4 * g + i < W) yo[i] = acc[i] + bv;
+                }
+            }
+        };
+        using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
+        using S2 = std::integral_constant<int, 2>;
+        // step(top, mid, bot): rows oy-1, oy, oy+1 are resident.  Once the top row's taps are issued its slot is
+        // free: row oy+2 is fetched into it, a whole step before it is needed (as the bottom row of step oy+1).
+        auto step = [&](auto top, auto mid, auto bot, int oy) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            row_mma(top, 0, acc);
+            load_row(top, oy + 2);
+            row_mma(mid, 1, acc); row_mma(bot, 2, acc);
+            out_row(oy, acc);
+        };
+        load_row(S0{}, y0 - 1); load_row(S1{}, y0); load_row(S2{}, y0 + 1);
+        for (int oy = y0; oy < y1; oy += 3) {
+            step(S0{}, S1{}, S2{}, oy);
+            if (oy + 1 < y1) step(S1{}, S2{}, S0{}, oy + 1);
+            if (oy + 2 < y1) step(S2{}, S0{}, S1{}, oy + 2);
+        }
+    }
+}
+
+template <typename T, int KS>
+static int conv_last_strip_launch(const void* x, const float* w, const float* bias, float* y, int b, int h, int wd, int cout,
+                                  hipStream_t st) {
+    const int rc = h >= 64 ? 32 : (h >= 16 ? 16 : h);
+    const long long nstrips = (long long)b * ((h + rc - 1) / rc) * ((wd + 15) / 16);
+    ADVS_REQUIRE(nstrips < (1ll << 31) - 4 * 8192 && (long long)b * h * wd * KS * 64 < (1ll << 62), "conv_last: shape out of range");
+    const int grid = (int)((nstrips + 3) / 4 < 2048 ? (nstrips + 3) / 4 : 2048);
+    conv_last_strip_kernel<T, KS><<<grid, 256, 0, st>>>((const T*)x, w, bias, y, b, h, wd, cout, rc, (const char*)advs_zero_page());
+    ADVS_CHECK_LAUNCH("conv_last");
+    return ADVS_OK;
+}
+
+template <typename T, int R, int KS>
+static int conv_last_mfma_launch(const void* x, const float* w, const float* bias, float* y, int b, int h, int wd, int cout,
+                                 hipStream_t st) {
+    const long long ntiles = (long long)b * h * ((wd + 15) / 16);
+    ADVS_REQUIRE(ntiles < (1ll << 31) - 4 * 8192, "conv_last: too many pixels for 32-bit tile indices");
+    const int grid = (int)((ntiles + 3) / 4 < 2048 ? (ntiles + 3) / 4 : 2048);     // persistent: 8 workgroups per CU
+    conv_last_mfma_kernel<T, R, KS><<<grid, 256, 0, st>>>((const T*)x, w, bias, y, b, h, wd, cout, (const char*)advs_zero_page());
+    ADVS_CHECK_LAUNCH("conv_last");
+    return ADVS_OK;
+}
+
+template <typename T>
+static int conv_last16_launch(const void* x, const float* w, const float* bias, float* y, int b, int cin, int h, int wd,
+                              int cout, int ksize, hipStream_t st) {
+    const size_t lds = (size_t)ksize * ksize * (cin / 8) * 3 * sizeof(u32x4);
+    ADVS_REQUIRE(lds <= 65536, "conv_last: cin=%d too large", cin);
+    const long long nruns = (long long)b * h * ((wd + 7) / 8);
+    ADVS_REQUIRE(nruns < (1ll << 31) - 16 * 16384, "conv_last: too many pixels for 32-bit run indices");
+    const int grid = (int)((nruns + 15) / 16 < 16384 ? (nruns + 15) / 16 : 16384);
+    if (ksize == 3) conv_last16_kernel<T, 3><<<grid, 256, lds, st>>>((const T*)x, w, bias, y, b, cin, h, wd, cout, (const u32x4*)advs_zero_page());
+    else conv_last16_kernel<T, 1><<<grid, 256, lds, st>>>((const T*)x, w, bias, y, b, cin, h, wd, cout, (const u32x4*)advs_zero_page());
+    ADVS_CHECK_LAUNCH("conv_last");
+    return ADVS_OK;
+}
+
 extern "C" int advs_conv_last(const void* x, const float* w, const float* bias, float* y,
                               int b, int cin, int h, int wd, int cout, int ksize, int dtype, void* stream) {
     ADVS_REQUIRE(x && w && y && b > 0 && h > 0 && wd > 0, "conv_last: bad args");
@@ -172,6 +501,21 @@ extern "C" int advs_conv_last(const void* x, const float* w, const float* bias, 
     ADVS_REQUIRE(ksize == 1 || ksize == 3, "conv_last: ksize %d unsupported", ksize);
     const int vec = dtype == ADVS_F32 ? 4 : 8;
     ADVS_REQUIRE(cin % vec == 0, "conv_last: cin=%d must be a multiple of %d", cin, vec);
+    if (cout <= 3 && dtype != ADVS_F32 && (cin == 128 || cin == 64)) {      // the UNets' widths: matrix-core kernel
+        const hipStream_t st = (hipStream_t)stream;
+        if (dtype == ADVS_BF16) {
+            if (ksize == 3) return cin == 128 ? conv_last_strip_launch<BF16, 4>(x, w, bias, y, b, h, wd, cout, st)
+                                              : conv_last_strip_launch<BF16, 2>(x, w, bias, y, b, h, wd, cout, st);
+            return cin == 128 ? conv_last_mfma_launch<BF16, 1, 4>(x, w, bias, y, b, h, wd, cout, st)
+                              : conv_last_mfma_launch<BF16, 1, 2>(x, w, bias, y, b, h, wd, cout, st);
+        }
+        if (ksize == 3) return cin == 128 ? conv_last_strip_launch<F16, 4>(x, w, bias, y, b, h, wd, cout, st)
+                                          : conv_last_strip_launch<F16, 2>(x, w, bias, y, b, h, wd, cout, st);
+        return cin == 128 ? conv_last_mfma_launch<F16, 1, 4>(x, w, bias, y, b, h, wd, cout, st)
+                          : conv_last_mfma_launch<F16, 1, 2>(x, w, bias, y, b, h, wd, cout, st);
+    }
+    if (cout <= 3 && dtype == ADVS_BF16) return conv_last16_launch<BF16>(x, w, bias, y, b, cin, h, wd, cout, ksize, (hipStream_t)stream);
+    if (cout <= 3 && dtype == ADVS_F16) return conv_last16_launch<F16>(x, w, bias, y, b, cin, h, wd, cout, ksize, (hipStream_t)stream);
     const size_t lds = (size_t)ksize * ksize * cin * 4 * sizeof(float);
     ADVS_REQUIRE(lds <= 65536, "conv_last: cin=%d too large", cin);
     const long long nruns = (long long)b * h * ((wd + CL_PX - 1) / CL_PX);
