@@ -38,6 +38,8 @@ SIGNATURES = {
     "advs_conv_tile_rows": [i32],
     "advs_groupnorm_stats": [vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "advs_conv3x3_first": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "advs_conv3x3_first_stats": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "advs_conv_first_stats_rows": [i32, i32, i32, i32, i32],
     "advs_conv_last": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "advs_groupnorm": [vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "advs_maxpool2": [vp, vp, i32, i32, i32, i32, i32, vp],

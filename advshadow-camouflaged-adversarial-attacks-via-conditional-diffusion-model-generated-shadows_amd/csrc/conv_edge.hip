@@ -73,11 +73,148 @@ conv3x3_first_kernel(const float* __restrict__ x, const float* __restrict__ w, c
     }
 }
 
-extern "C" int advs_conv3x3_first(const float* x, const float* w, const float* bias, void* y,
-                                  int b, int cin, int h, int wd, int cout, int dtype, void* stream) {
+typedef __attribute__((ext_vector_type(8))) __bf16 mbf16x8;
+template <typename T> __device__ __forceinline__ f32x4 mma16x16(const u32x4& a, const u32x4& b, const f32x4& c);
+template <> __device__ __forceinline__ f32x4 mma16x16<BF16>(const u32x4& a, const u32x4& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mbf16x8, a), __builtin_bit_cast(mbf16x8, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x4 mma16x16<F16>(const u32x4& a, const u32x4& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+
+// ---------------------------------------------------------------- first conv on the matrix cores (16-bit modes)
+// K = 9 * cin <= 32 is ONE k-step of v_mfma_f32_16x16x32.  The product is computed transposed -- A = weights
+// (16 channels x K), B = im2col (K x 16 pixels) -- so a lane ends up with 4 consecutive channels of ITS pixel;
+// two tiles whose channel rows interleave (32j + 8g + {0..3} and + {4..7}) give it 8 consecutive channels = one
+// 16-byte NHWC store.  The im2col fragment is gathered straight from the NCHW f32 input (8 cached scalar loads
+// per lane).  A wave owns a contiguous chunk of FS_TILES 16-pixel tiles of one image and (optionally) leaves
+// per-channel (sum, sum of squares) of the ROUNDED outputs of that chunk for the GroupNorm that follows
+// (same [row block][channel][2] layout as advs_conv2d's epilogue statistics).
+#define FS_TILES 64                              // 1024 pixels per statistics block
+template <typename T, int NP>
+__global__ void __launch_bounds__(256)
+conv_first_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                       T* __restrict__ y, float* __restrict__ stats, int B, int Cin, int H, int W) {
+    constexpr int Cout = NP * 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, g = lane >> 4, K = Cin * 9, HW = H * W;
+    // A fragments: tile (pair j, half hh), row n <-> channel 32j + 8(n>>2) + 4hh + (n&3); k = 8g .. 8g+7
+    u32x4 af[NP][2];
+    float bv[NP][8];
+#pragma unroll
+    for (int j = 0; j < NP; ++j)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int ch = 32 * j + 8 * (n >> 2) + 4 * hh + (n & 3);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k0 = 8 * g + 2 * q;
+                af[j][hh][q] = pack2<T>(k0 < K ? w[(size_t)ch * K + k0] : 0.f, k0 + 1 < K ? w[(size_t)ch * K + k0 + 1] : 0.f);
+            }
+        }
+#pragma unroll
+    for (int j = 0; j < NP; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bv[j][i] = bias ? bias[32 * j + 8 * g + i] : 0.f;      // D rows of this lane
+    // im2col taps of this lane: k = 8g + q -> (channel, dy, dx)
+    int tc[8], tdy[8], tdx[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int k = 8 * g + q, c = k / 9, r9 = k - 9 * c;
+        tc[q] = k < K ? c : -1; tdy[q] = r9 / 3 - 1; tdx[q] = r9 % 3 - 1;
+    }
+    const int cpi = HW / (16 * FS_TILES) > 0 ? (HW + 16 * FS_TILES - 1) / (16 * FS_TILES) : 1;     // chunks per image
+    const int nchunks = B * cpi, tiles_img = HW >> 4;
+    for (int chunk = blockIdx.x * 4 + wave; chunk < nchunks; chunk += gridDim.x * 4) {
+        const int b = chunk / cpi, ci = chunk - b * cpi;
+        const int t0 = ci * FS_TILES, t1 = min(tiles_img, t0 + FS_TILES);
+        float ssum[NP][8], ssq[NP][8];
+#pragma unroll
+        for (int j = 0; j < NP; ++j)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { ssum[j][i] = 0.f; ssq[j][i] = 0.f; }
+        const float* xb = x + (size_t)b * Cin * HW;
+        for (int t = t0; t < t1; ++t) {
+            const int p = t * 16 + n, oy = p / W, ox = p - oy * W;
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int iy = oy + tdy[q], ix = ox + tdx[q];
+                const bool ok = tc[q] >= 0 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                const float* src = ok ? xb + ((size_t)tc[q] * H + iy) * W + ix : xb;
+                const float val = *src;
+                v[q] = ok ? val : 0.f;
+            }
+            const u32x4 bf = u32x4{pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7])};
+            T* yo = y + ((size_t)b * HW + p) * Cout + 8 * g;
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 d0 = mma16x16<T>(af[j][0], bf, z), d1 = mma16x16<T>(af[j][1], bf, z);
+                float o[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { o[i] = d0[i] + bv[j][i]; o[4 + i] = d1[i] + bv[j][4 + i]; }
+                const u32x4 packed = pack16<T>(o);
+                *(u32x4*)(yo + 32 * j) = packed;
+                if (stats) {
+                    float rr[8];
+                    unpack16<T>(packed, rr);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { ssum[j][i] += rr[i]; ssq[j][i] = fmaf(rr[i], rr[i], ssq[j][i]); }
+                }
+            }
+        }
+        if (stats) {                              // fold the 16 pixel lanes, fixed order; lane n == 0 writes
+#pragma unroll
+            for (int j = 0; j < NP; ++j)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float a = ssum[j][i], q2 = ssq[j][i];
+#pragma unroll
+                    for (int m = 8; m > 0; m >>= 1) { a += __shfl_xor(a, m); q2 += __shfl_xor(q2, m); }
+                    if (n == 0) {
+                        float* so = stats + (((size_t)b * cpi + ci) * Cout + 32 * j + 8 * g + i) * 2;
+                        so[0] = a; so[1] = q2;
+                    }
+                }
+        }
+    }
+}
+
+// Pixels per statistics block of the MFMA first conv for this shape, or 0 when that path (or its statistics)
+// does not apply: 16-bit dtype, 9 * cin <= 32, cout 64 or 128, w a multiple of 16, h * w a multiple of 1024.
+extern "C" int advs_conv_first_stats_rows(int cin, int h, int w, int cout, int dtype) {
+    if (dtype == ADVS_F32 || cin < 1 || cin * 9 > 32 || (cout != 64 && cout != 128) || w % 16) return 0;
+    return ((long long)h * w) % (16 * FS_TILES) == 0 ? 16 * FS_TILES : 0;
+}
+
+template <typename T>
+static int conv_first_mfma_launch(const float* x, const float* w, const float* bias, void* y, float* stats, int b, int cin,
+                                  int h, int wd, int cout, hipStream_t st) {
+    const long long hw = (long long)h * wd;
+    ADVS_REQUIRE(hw * b < (1ll << 31), "conv3x3_first: too many pixels");
+    const long long cpi = (hw + 16 * FS_TILES - 1) / (16 * FS_TILES);
+    const long long nchunks = cpi * b;
+    const int grid = (int)((nchunks + 3) / 4 < 4096 ? (nchunks + 3) / 4 : 4096);
+    if (cout == 128) conv_first_mfma_kernel<T, 4><<<grid, 256, 0, st>>>(x, w, bias, (T*)y, stats, b, cin, h, wd);
+    else conv_first_mfma_kernel<T, 2><<<grid, 256, 0, st>>>(x, w, bias, (T*)y, stats, b, cin, h, wd);
+    ADVS_CHECK_LAUNCH("conv3x3_first");
+    return ADVS_OK;
+}
+
+extern "C" int advs_conv3x3_first_stats(const float* x, const float* w, const float* bias, void* y, float* stats,
+                                        int b, int cin, int h, int wd, int cout, int dtype, void* stream) {
     ADVS_REQUIRE(x && w && y && b > 0 && h > 0 && wd > 0, "conv3x3_first: bad args");
     ADVS_REQUIRE(cin >= 1 && cin <= 4, "conv3x3_first: cin=%d must be <= 4", cin);
     ADVS_REQUIRE(cout % 8 == 0 && cout <= 512, "conv3x3_first: cout=%d must be a multiple of 8, <= 512", cout);
+    const bool mfma = dtype != ADVS_F32 && cin * 9 <= 32 && (cout == 64 || cout == 128) && wd % 16 == 0;
+    ADVS_REQUIRE(!stats || advs_conv_first_stats_rows(cin, h, wd, cout, dtype) > 0,
+                 "conv3x3_first: statistics are not available for this shape (advs_conv_first_stats_rows == 0)");
+    if (mfma) {
+        if (dtype == ADVS_BF16) return conv_first_mfma_launch<BF16>(x, w, bias, y, stats, b, cin, h, wd, cout, (hipStream_t)stream);
+        return conv_first_mfma_launch<F16>(x, w, bias, y, stats, b, cin, h, wd, cout, (hipStream_t)stream);
+    }
     const size_t lds = ((size_t)cin * 9 * cout + cout) * sizeof(float);
     const long long nruns = (long long)b * h * ((wd + CF_PX - 1) / CF_PX);
     const int gpb = 256 / (cout / 8);
@@ -85,6 +222,11 @@ extern "C" int advs_conv3x3_first(const float* x, const float* w, const float* b
     ADVS_SWITCH_T(dtype, conv3x3_first_kernel<T><<<grid, 256, lds, (hipStream_t)stream>>>(x, w, bias, (T*)y, b, cin, h, wd, cout));
     ADVS_CHECK_LAUNCH("conv3x3_first");
     return ADVS_OK;
+}
+
+extern "C" int advs_conv3x3_first(const float* x, const float* w, const float* bias, void* y,
+                                  int b, int cin, int h, int wd, int cout, int dtype, void* stream) {
+    return advs_conv3x3_first_stats(x, w, bias, y, nullptr, b, cin, h, wd, cout, dtype, stream);
 }
 
 // ---------------------------------------------------------------- last conv: NHWC T -> NCHW f32
@@ -284,15 +426,6 @@ conv_last16_kernel(const T* __restrict__ x, const float* __restrict__ w, const f
 // re-read the shifted pixels through L1.  The B fragments (weights, TAPS x Cin/32 of them) are read from LDS
 // (36 KiB at Cin = 128; in registers they would cost 144 VGPRs and the occupancy that hides the load latency).  36 MFMAs of 16 cycles per 16 pixels replace ~860
 // multi-cycle dot2 instructions per 32.
-typedef __attribute__((ext_vector_type(8))) __bf16 mbf16x8;
-template <typename T> __device__ __forceinline__ f32x4 mma16x16(const u32x4& a, const u32x4& b, const f32x4& c);
-template <> __device__ __forceinline__ f32x4 mma16x16<BF16>(const u32x4& a, const u32x4& b, const f32x4& c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mbf16x8, a), __builtin_bit_cast(mbf16x8, b), c, 0, 0, 0);
-}
-template <> __device__ __forceinline__ f32x4 mma16x16<F16>(const u32x4& a, const u32x4& b, const f32x4& c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-}
-
 template <typename T, int R, int KS>
 __global__ void __launch_bounds__(256)
 conv_last_mfma_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,

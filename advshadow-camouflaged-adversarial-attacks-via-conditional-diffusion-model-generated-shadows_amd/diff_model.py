@@ -311,7 +311,7 @@ def emit_unet_forward(bld, model, W, x_nchw, t_dev, eps_out):
     def run_stage(stage, h, skip):
         for kind, p, cin, cout in stage:
             if kind == "stem":
-                new = bld.conv_first(x_nchw, W[p + ".w"], W[p + ".b"], cout)
+                new = bld.conv_first(x_nchw, W[p + ".w"], W[p + ".b"], cout, want_stats=True)
             elif kind == "res":
                 new = res_block(p, cin, cout, h, skip)
                 skip = None

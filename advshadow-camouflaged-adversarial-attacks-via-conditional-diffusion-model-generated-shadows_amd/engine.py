@@ -177,11 +177,16 @@ class Builder:
         self.plan.add(self.lib.advs_conv2d, C.byref(a), keep=(a, x1, x2, w, bias, temb, residual, y, stats, extra))
         return y
 
-    def conv_first(self, x_nchw, w, bias, cout):
+    def conv_first(self, x_nchw, w, bias, cout, want_stats=False):
         B, Cin, H, W = x_nchw.shape
         y = self.buf((B, H, W, cout))
-        self.plan.add(self.lib.advs_conv3x3_first, ptr(x_nchw), ptr(w), ptr(bias), ptr(y), B, Cin, H, W, cout, self.dt,
-                      keep=(x_nchw, w, bias, y))
+        stats = None
+        rows = self.lib.advs_conv_first_stats_rows(Cin, H, W, cout, self.dt) if want_stats else 0
+        if rows > 0:
+            stats = self.buf((B * H * W // rows, cout, 2), torch.float32)
+            self.stats[y.data_ptr()] = (stats, H * W // rows)
+        self.plan.add(self.lib.advs_conv3x3_first_stats, ptr(x_nchw), ptr(w), ptr(bias), ptr(y), ptr(stats), B, Cin, H, W,
+                      cout, self.dt, keep=(x_nchw, w, bias, y, stats))
         return y
 
     def conv_last(self, x, w, bias, cout, ksize, out_nchw):

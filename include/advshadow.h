@@ -91,6 +91,13 @@ int advs_conv_tile_rows(int tile);      /* row-block height (rows per stats entr
  * model/modules/conv.py:38 for inc).  w is the torch OIHW f32 weight.                      */
 int advs_conv3x3_first(const float* x_nchw, const float* w_oihw, const float* bias, void* y,
                        int b, int cin, int h, int w, int cout, int dtype, void* stream);
+/* Same, optionally leaving per-channel (sum, sum of squares) of the rounded outputs per block of
+ * advs_conv_first_stats_rows() pixels -- stats[b * (h*w/rows) + block][cout][2], the layout advs_groupnorm_stats
+ * folds -- so the first GroupNorm (diff_model.py:70) needs no statistics pass.  stats may be NULL.
+ * advs_conv_first_stats_rows returns 0 when the shape has no statistics path (f32, cin > 3, odd sizes).      */
+int advs_conv_first_stats_rows(int cin, int h, int w, int cout, int dtype);
+int advs_conv3x3_first_stats(const float* x, const float* w, const float* bias, void* y, float* stats,
+                             int b, int cin, int h, int wd, int cout, int dtype, void* stream);
 /* Last conv: NHWC `dtype` (cin multiple of 8) -> NCHW f32 with cout <= 4 (diff_model.py:242,
  * ksize 3; model/networks/unet.py:92, ksize 1).  w is the torch OIHW f32 weight.           */
 int advs_conv_last(const void* x, const float* w_oihw, const float* bias, float* y_nchw,

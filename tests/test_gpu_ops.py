@@ -105,7 +105,8 @@ def test_pack_conv_weight(dt):
 
 
 @pytest.mark.parametrize("dt", DTS)
-@pytest.mark.parametrize("shape", [(2, 3, 16, 16, 64), (1, 3, 9, 13, 128), (1, 1, 8, 8, 32)])
+@pytest.mark.parametrize("shape", [(2, 3, 16, 16, 64), (1, 3, 9, 13, 128), (1, 1, 8, 8, 32), (2, 3, 40, 48, 128), (1, 2, 16, 32, 64),
+                                   (1, 3, 24, 16, 32)])
 def test_conv_first(shape, dt):
     B, Cin, H, W, Cout = shape
     x, w, b = rnd(B, Cin, H, W, seed=1), rnd(Cout, Cin, 3, 3, seed=2, scale=0.2), rnd(Cout, seed=3)
@@ -115,6 +116,32 @@ def test_conv_first(shape, dt):
     op.go()
     err = (nchw(y) - ref).abs().max().item()
     assert err < tol(dt, 1e-5, 3e-2), err
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_conv_first_statistics_feed_groupnorm(dt):
+    """The MFMA first conv leaves per-channel statistics of its rounded outputs: the GroupNorm that follows
+    (diff_model.py:70) must equal GroupNorm of the stored tensor, alone and as the second half of a concat."""
+    B, Cin, H, W, Cout = 2, 3, 64, 32, 128
+    x, w, b = rnd(B, Cin, H, W, seed=81), rnd(Cout, Cin, 3, 3, seed=82, scale=0.2), rnd(Cout, seed=83)
+    g, be = rnd(2 * Cout, seed=84) + 1, rnd(2 * Cout, seed=85)
+    other = rnd(B, Cout, H, W, seed=86)
+    op = OneOp(dt, B)
+    y = op.b.conv_first(x.to(dev()), w.to(dev()), b.to(dev()), Cout, want_stats=True)
+    has = y.data_ptr() in op.b.stats
+    assert has == (dt != "fp32")                                        # f32 keeps the direct kernel (no statistics)
+    n1 = op.b.groupnorm(y, g[:Cout].to(dev()), be[:Cout].to(dev()), 32, act="silu")
+    o = op.b.conv(nhwc(other, dt), pack_conv_weight(torch.eye(Cout).reshape(Cout, Cout, 1, 1).to(dev()), dtype_code(dt)),
+                  Cout, ksize=1, pad=0, want_stats=True)                # identity 1x1: a conv-produced tensor with statistics
+    n2 = op.b.groupnorm(o, g.to(dev()), be.to(dev()), 32, x2=y)         # norm of cat([o, y])
+    op.go()
+    ys = nchw(y)                                                        # stored (rounded) conv output
+    err = (ys - F.conv2d(x, w, b, padding=1)).abs().max().item()
+    assert err < tol(dt, 1e-5, 3e-2), err
+    ref1 = F.silu(F.group_norm(ys, 32, g[:Cout], be[:Cout], eps=1e-5))
+    assert (nchw(n1) - ref1).abs().max().item() < tol(dt, 2e-5, 4e-2)
+    ref2 = F.group_norm(torch.cat([nchw(o), ys], 1), 32, g, be, eps=1e-5)
+    assert (nchw(n2) - ref2).abs().max().item() < tol(dt, 2e-5, 4e-2)
 
 
 @pytest.mark.parametrize("dt", DTS)
