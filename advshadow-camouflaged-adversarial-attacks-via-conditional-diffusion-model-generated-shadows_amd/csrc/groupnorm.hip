@@ -156,7 +156,9 @@ gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ x2, int C1, const
     for (; p + 3 * PIXB < p1; p += 4 * PIXB) {                     // four 16-byte loads in flight per lane
         const size_t i0 = (size_t)p * vs, i1 = (size_t)(p + PIXB) * vs, i2 = (size_t)(p + 2 * PIXB) * vs,
                      i3 = (size_t)(p + 3 * PIXB) * vs;
-        const u32x4 a0 = xb[i0], a1 = xb[i1], a2 = xb[i2], a3 = xb[i3];
+        // x is dead after this pass: stream it past the caches (nontemporal), they are better spent on y
+        const u32x4 a0 = __builtin_nontemporal_load(xb + i0), a1 = __builtin_nontemporal_load(xb + i1),
+                    a2 = __builtin_nontemporal_load(xb + i2), a3 = __builtin_nontemporal_load(xb + i3);
         u32x4 r0 = a0, r1 = a0, r2 = a0, r3 = a0;
         if (rb) {
             r0 = rb[(size_t)p * vpp]; r1 = rb[(size_t)(p + PIXB) * vpp];
