@@ -158,12 +158,22 @@ def main():
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
         args.gpus = world
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    # one rank per GPU; ADVS_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (ranks
+    # then share devices and the control plane runs over gloo; the numbers of such a run mean nothing)
+    backend = os.environ.get("ADVS_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if world > 1 and backend == "nccl" and local >= ndev:
+        raise SystemExit(f"bench.py: LOCAL_RANK {local} but only {ndev} GPU(s) visible")
+    local_dev = local % max(ndev, 1)
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from advshadow_amd.diff_model import GaussianDiffusion, UNetModel
 
@@ -193,7 +203,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     assert torch.isfinite(out).all().item(), "non-finite samples"
