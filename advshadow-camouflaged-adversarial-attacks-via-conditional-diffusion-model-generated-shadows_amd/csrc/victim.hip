@@ -206,3 +206,86 @@ extern "C" int advs_gather_rows_f32(const void* x, float* y, int b, long long ro
     ADVS_CHECK_LAUNCH("gather_rows_f32");
     return ADVS_OK;
 }
+
+// ================================================================ ConvNeXt pieces (timm convnext_base, ASR_fast.py:21-26)
+// Depthwise k x k convolution (groups = C), stride 1 or 2, 'same' padding k/2, on NHWC activations:
+// y[b][oy][ox][c] = bias[c] + sum_t x[b][oy*s + ky - k/2][ox*s + kx - k/2][c] * w[t][c].  A lane owns one 16-byte
+// channel vector of one output pixel; the weights are pre-transposed by the host to [k*k][C] f32 so that a tap's
+// weights for the lane's channels are contiguous (cached: every pixel of the image re-reads them).  HBM-bound
+// (reads x once through L2, writes y once).
+template <typename T>
+__global__ void __launch_bounds__(256)
+dwconv_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, T* __restrict__ y,
+              int B, int H, int W, int C, int K, int stride, int Ho, int Wo) {
+    constexpr int VEC = Elt<T>::VEC;
+    const int vpp = C / VEC, pad = K / 2;
+    const size_t total = (size_t)B * Ho * Wo * vpp;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % vpp);
+        size_t r = i / vpp;
+        const int ox = (int)(r % Wo); r /= Wo;
+        const int oy = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        float acc[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] = bias ? bias[cv * VEC + e] : 0.f;
+        for (int ky = 0; ky < K; ++ky) {
+            const int iy = oy * stride + ky - pad;
+            if ((unsigned)iy >= (unsigned)H) continue;
+            for (int kx = 0; kx < K; ++kx) {
+                const int ix = ox * stride + kx - pad;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                float f[VEC];
+                unpack16<T>(*((const u32x4*)(x + (((size_t)b * H + iy) * W + ix) * C) + cv), f);
+                const float* wt = w + (size_t)(ky * K + kx) * C + cv * VEC;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[e] = fmaf(f[e], wt[e], acc[e]);
+            }
+        }
+        *((u32x4*)(y + (((size_t)b * Ho + oy) * Wo + ox) * C) + cv) = pack16<T>(acc);
+    }
+}
+
+extern "C" int advs_dwconv2d(const void* x, const float* w_taps_c, const float* bias, void* y, int b, int h, int w, int c,
+                             int ksize, int stride, int dtype, void* stream) {
+    ADVS_REQUIRE(x && w_taps_c && y && b > 0 && h > 0 && w > 0 && c > 0, "dwconv2d: bad args");
+    ADVS_REQUIRE((ksize & 1) && ksize >= 1 && ksize <= 7 && (stride == 1 || stride == 2), "dwconv2d: ksize %d / stride %d unsupported", ksize, stride);
+    const int vec = dtype == ADVS_F32 ? 4 : 8;
+    ADVS_REQUIRE(c % vec == 0, "dwconv2d: c=%d must be a multiple of %d", c, vec);
+    const int ho = (h + 2 * (ksize / 2) - ksize) / stride + 1, wo = (w + 2 * (ksize / 2) - ksize) / stride + 1;
+    const size_t total = (size_t)b * ho * wo * (c / vec);
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    ADVS_SWITCH_T(dtype, dwconv_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T*)x, w_taps_c, bias, (T*)y, b, h, w, c, ksize, stride, ho, wo));
+    ADVS_CHECK_LAUNCH("dwconv2d");
+    return ADVS_OK;
+}
+
+// space-to-depth by 2: [b][h][w][c] -> [b][h/2][w/2][4c], output channel (dy*2 + dx)*c + ch -- the K order of a
+// Conv2d(c, cout, 2, stride 2) weight packed as [cout][dy][dx][c] (advs_pack_conv_weight), so the ConvNeXt
+// downsampling conv is a 1x1 advs_conv2d on the result.
+template <typename T>
+__global__ void space_to_depth2_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C) {
+    constexpr int VEC = Elt<T>::VEC;
+    const int vpp = C / VEC, Ho = H / 2, Wo = W / 2;
+    const size_t total = (size_t)B * Ho * Wo * 4 * vpp;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % vpp);
+        size_t r = i / vpp;
+        const int q = (int)(r % 4); r /= 4;
+        const int ox = (int)(r % Wo); r /= Wo;
+        const int oy = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        ((u32x4*)y)[i] = *((const u32x4*)(x + (((size_t)b * H + 2 * oy + (q >> 1)) * W + 2 * ox + (q & 1)) * C) + cv);
+    }
+}
+
+extern "C" int advs_space_to_depth2(const void* x, void* y, int b, int h, int w, int c, int dtype, void* stream) {
+    ADVS_REQUIRE(x && y && b > 0 && h > 0 && w > 0 && h % 2 == 0 && w % 2 == 0, "space_to_depth2: bad shape");
+    const int vec = dtype == ADVS_F32 ? 4 : 8;
+    ADVS_REQUIRE(c % vec == 0, "space_to_depth2: c=%d must be a multiple of %d", c, vec);
+    const size_t total = (size_t)b * h * w * (c / vec);
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    ADVS_SWITCH_T(dtype, space_to_depth2_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T*)x, (T*)y, b, h, w, c));
+    ADVS_CHECK_LAUNCH("space_to_depth2");
+    return ADVS_OK;
+}

@@ -432,3 +432,190 @@ class _VGGEngine(_ResNetEngine):
             self.logits = bld.linear(f, W["fc6.w"], W["fc6.b"])
             self.plan, self.captured = bld.plan, False
             torch.cuda.synchronize(dev)
+
+
+# ============================================================================ ConvNeXt (timm names)
+_CONVNEXT_BASE = dict(depths=(3, 3, 27, 3), dims=(128, 256, 512, 1024))
+
+
+def convnext_canonical_state_dict(sd):
+    """Accept HF ``ConvNextForImageClassification`` keys as well as timm's (the reference's loader,
+    ASR_fast.py:21-26, is timm): returns timm-style names."""
+    if not any(k.startswith("convnext.") or k.startswith("classifier.") for k in sd):
+        return dict(sd)
+    out = {}
+    for k, v in sd.items():
+        n = k.replace("convnext.layernorm.", "head.norm.").replace("classifier.", "head.fc.")
+        n = n.replace("convnext.embeddings.patch_embeddings.", "stem.0.").replace("convnext.embeddings.layernorm.", "stem.1.")
+        n = n.replace("convnext.encoder.stages.", "stages.").replace(".downsampling_layer.", ".downsample.")
+        n = n.replace(".layers.", ".blocks.").replace(".dwconv.", ".conv_dw.").replace(".layernorm.", ".norm.")
+        n = n.replace(".pwconv1.", ".mlp.fc1.").replace(".pwconv2.", ".mlp.fc2.").replace(".layer_scale_parameter", ".gamma")
+        out[n] = v
+    return out
+
+
+class ConvNeXtVictim(nn.Module):
+    """``timm.create_model('convnext_base.fb_in1k', num_classes=37)`` (ASR_fast.py:21-26) on the HIP kernels.
+    Parameter names follow timm (``stem.{0,1}``, ``stages.i.downsample.{0,1}``, ``stages.i.blocks.j.{conv_dw,norm,
+    mlp.fc1,mlp.fc2,gamma}``, ``head.norm``, ``head.fc``); HF ConvNext names are accepted by load_state_dict.
+    Block: depthwise 7x7 -> LayerNorm -> Linear(C,4C)+GELU -> Linear(4C,C) with the layer scale folded in
+    (+ residual in the GEMM epilogue).  The 4x4/s4 stem and the 2x2/s2 downsampling convs are patch gathers
+    followed by 1x1 GEMMs.  ``head_norm_eps``: 1e-6 (timm) / 1e-12 (HF's config.layer_norm_eps)."""
+
+    def __init__(self, num_classes=37, depths=_CONVNEXT_BASE["depths"], dims=_CONVNEXT_BASE["dims"], image_size=224,
+                 head_norm_eps=1e-6, compute_dtype="fp32", use_graph=True):
+        super().__init__()
+        self.num_classes, self.depths, self.dims, self.image_size = num_classes, tuple(depths), tuple(dims), image_size
+        self.head_norm_eps, self.compute_dtype, self.use_graph = head_norm_eps, compute_dtype, use_graph
+        _attach(self, "stem.0", nn.Conv2d(3, dims[0], 4, stride=4))
+        _attach(self, "stem.1", nn.LayerNorm(dims[0], eps=1e-6))
+        for i, (n, c) in enumerate(zip(depths, dims)):
+            if i > 0:
+                _attach(self, f"stages.{i}.downsample.0", nn.LayerNorm(dims[i - 1], eps=1e-6))
+                _attach(self, f"stages.{i}.downsample.1", nn.Conv2d(dims[i - 1], c, 2, stride=2))
+            for j in range(n):
+                p = f"stages.{i}.blocks.{j}"
+                _attach(self, p + ".conv_dw", nn.Conv2d(c, c, 7, padding=3, groups=c))
+                _attach(self, p + ".norm", nn.LayerNorm(c, eps=1e-6))
+                _attach(self, p + ".mlp.fc1", nn.Linear(c, 4 * c))
+                _attach(self, p + ".mlp.fc2", nn.Linear(4 * c, c))
+                self.register_parameter(p.replace(".", "__") + "__gamma", nn.Parameter(torch.full((c,), 1e-6)))
+        _attach(self, "head.norm", nn.LayerNorm(dims[-1], eps=1e-6))
+        _attach(self, "head.fc", nn.Linear(dims[-1], num_classes))
+        self._packed, self._engines = {}, {}
+
+    # gamma is a bare Parameter of the block in timm ("stages.i.blocks.j.gamma"): expose it under that name
+    def state_dict(self, *a, **k):
+        sd = super().state_dict(*a, **k)
+        return type(sd)((kk.replace("__gamma", ".gamma").replace("__", ".") if kk.endswith("__gamma") else kk, v) for kk, v in sd.items())
+
+    def load_state_dict(self, sd, strict=True, **k):
+        sd = convnext_canonical_state_dict(sd)
+        sd = {(kk[:-len(".gamma")].replace(".", "__") + "__gamma" if kk.endswith(".gamma") else kk): v for kk, v in sd.items()}
+        return super().load_state_dict(sd, strict=strict, **k)
+
+    def _version(self):
+        dev = next(self.parameters()).device
+        return (str(dev), sum(p._version for p in self.parameters()))
+
+    def packed_weights(self, dt):
+        ver = self._version()
+        hit = self._packed.get(dt)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise _lib.AdvsError(f"ConvNeXtVictim parameters are on {dev}: move the model to the GPU; there is no CPU fallback")
+        sd = {k: v.detach() for k, v in self.state_dict().items()}
+        f32 = lambda k: sd[k].float().contiguous()
+        W = {"stem.w": pack_conv_weight(sd["stem.0.weight"].float().reshape(self.dims[0], -1, 1, 1), dt), "stem.b": f32("stem.0.bias"),
+             "stem.g": f32("stem.1.weight"), "stem.beta": f32("stem.1.bias")}
+        for i, (n, c) in enumerate(zip(self.depths, self.dims)):
+            if i > 0:
+                p = f"stages.{i}.downsample"
+                W[p + ".g"], W[p + ".beta"] = f32(p + ".0.weight"), f32(p + ".0.bias")
+                # [cout][cin][2][2] -> [cout][dy][dx][cin] = the channel order of advs_space_to_depth2
+                W[p + ".w"] = pack_conv_weight(sd[p + ".1.weight"], dt).reshape(c, 1, 1, -1)
+                W[p + ".b"] = f32(p + ".1.bias")
+            for j in range(n):
+                p = f"stages.{i}.blocks.{j}"
+                W[p + ".dw.w"] = sd[p + ".conv_dw.weight"].float().reshape(c, 49).t().contiguous()      # [49][c]
+                W[p + ".dw.b"] = f32(p + ".conv_dw.bias")
+                W[p + ".g"], W[p + ".beta"] = f32(p + ".norm.weight"), f32(p + ".norm.bias")
+                W[p + ".fc1.w"] = pack_conv_weight(sd[p + ".mlp.fc1.weight"].float().reshape(4 * c, c, 1, 1), dt)
+                W[p + ".fc1.b"] = f32(p + ".mlp.fc1.bias")
+                gamma = sd[p + ".gamma"].float()
+                W[p + ".fc2.w"] = pack_conv_weight((sd[p + ".mlp.fc2.weight"].float() * gamma[:, None]).reshape(c, 4 * c, 1, 1), dt)
+                W[p + ".fc2.b"] = (sd[p + ".mlp.fc2.bias"].float() * gamma).contiguous()
+        W["head.g"], W["head.beta"] = f32("head.norm.weight"), f32("head.norm.bias")
+        W["head.w"], W["head.b"] = f32("head.fc.weight"), f32("head.fc.bias")
+        self._packed[dt] = (ver, W)
+        for key in [k for k in self._engines if k[1] == dt]:
+            del self._engines[key]
+        return W
+
+    def engine(self, batch, dtype=None):
+        dt = dtype_code(dtype if dtype is not None else self.compute_dtype)
+        W = self.packed_weights(dt)
+        eng = self._engines.get((batch, dt))
+        if eng is None:
+            eng = _ConvNeXtEngine(self, W, batch, dt)
+            self._engines[(batch, dt)] = eng
+        return eng
+
+    def forward(self, x):
+        B = x.shape[0]
+        if x.shape[2] != self.image_size or x.shape[3] != self.image_size:
+            raise ValueError(f"ConvNeXtVictim was built for {self.image_size}x{self.image_size} inputs, got {tuple(x.shape[2:])}")
+        eng = self.engine(B)
+        cur = torch.cuda.current_stream(x.device)
+        eng.stream.wait_stream(cur)
+        with torch.cuda.stream(eng.stream):
+            eng.x.copy_(x.to(torch.float32), non_blocking=True)
+            eng.run()
+            out = eng.logits.clone()
+        cur.wait_stream(eng.stream)
+        out.record_stream(cur)
+        return out
+
+
+class _ConvNeXtEngine:
+    def __init__(self, model, W, batch, dt):
+        dev = next(model.parameters()).device
+        self.model, self.stream = model, torch.cuda.Stream(device=dev)
+        S, dims = model.image_size, model.dims
+        if S % 32:
+            raise ValueError("ConvNeXtVictim: image_size must be a multiple of 32 (4x stem, three 2x downsamplings)")
+        with torch.cuda.device(dev):
+            bld = Builder(dev, dt, self.stream, batch)
+            lib = bld.lib
+            self.x = torch.zeros((batch, 3, S, S), dtype=torch.float32, device=dev)
+            g = S // 4
+            patches = bld.buf((batch, g, g, 48))
+            bld.plan.add(lib.advs_patchify, ptr(self.x), ptr(patches), batch, 3, S, S, 4, dt, keep=(self.x, patches))
+            e = bld.conv(patches, W["stem.w"], dims[0], bias=W["stem.b"], ksize=1, pad=0)
+            bld.free(patches)
+            h = bld.layernorm(e, W["stem.g"], W["stem.beta"], 1e-6)
+            bld.free(e)
+            side = g
+            for i, (n, c) in enumerate(zip(model.depths, dims)):
+                if i > 0:
+                    p = f"stages.{i}.downsample"
+                    ln = bld.layernorm(h, W[p + ".g"], W[p + ".beta"], 1e-6)
+                    bld.free(h)
+                    s2d = bld.buf((batch, side // 2, side // 2, 4 * dims[i - 1]))
+                    bld.plan.add(lib.advs_space_to_depth2, ptr(ln), ptr(s2d), batch, side, side, dims[i - 1], dt, keep=(ln, s2d))
+                    bld.free(ln)
+                    side //= 2
+                    h = bld.conv(s2d, W[p + ".w"], c, bias=W[p + ".b"], ksize=1, pad=0)
+                    bld.free(s2d)
+                for j in range(n):
+                    p = f"stages.{i}.blocks.{j}"
+                    d = bld.buf((batch, side, side, c))
+                    bld.plan.add(lib.advs_dwconv2d, ptr(h), ptr(W[p + ".dw.w"]), ptr(W[p + ".dw.b"]), ptr(d), batch, side, side, c,
+                                 7, 1, dt, keep=(h, d))
+                    ln = bld.layernorm(d, W[p + ".g"], W[p + ".beta"], 1e-6)
+                    bld.free(d)
+                    f = bld.conv(ln, W[p + ".fc1.w"], 4 * c, bias=W[p + ".fc1.b"], act="gelu", ksize=1, pad=0)
+                    bld.free(ln)
+                    new = bld.conv(f, W[p + ".fc2.w"], c, bias=W[p + ".fc2.b"], residual=h, ksize=1, pad=0)
+                    bld.free(f)
+                    bld.free(h)
+                    h = new
+            pooled = bld.buf((batch, dims[-1]), torch.float32)
+            bld.plan.add(lib.advs_global_avgpool, ptr(h), ptr(pooled), batch, side * side, dims[-1], dt, keep=(h, pooled))
+            bld.free(h)
+            normed = bld.buf((batch, dims[-1]), torch.float32)
+            bld.plan.add(lib.advs_layernorm, ptr(pooled), ptr(W["head.g"]), ptr(W["head.beta"]), ptr(normed), batch, dims[-1],
+                         float(model.head_norm_eps), _lib.F32, keep=(pooled, normed))
+            self.logits = bld.linear(normed, W["head.w"], W["head.b"])
+            self.plan, self.captured = bld.plan, False
+            torch.cuda.synchronize(dev)
+
+    def run(self):
+        if self.model.use_graph and not self.captured:
+            self.plan.run_eager()
+            self.stream.synchronize()
+            self.plan.capture()
+            self.captured = True
+        self.plan.run()

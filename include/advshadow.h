@@ -246,6 +246,14 @@ int advs_conv_stem(const float* x_nchw, const float* w_oihw, const float* bias, 
 int advs_maxpool3x3s2(const void* x, void* y, int b, int h, int w, int c, int dtype, void* stream); /* MaxPool2d(3,2,1) */
 int advs_global_avgpool(const void* x, float* y, int b, int hw, int c, int dtype, void* stream);    /* -> f32 [b][c] */
 
+/* ---- ConvNeXt victim pieces (timm convnext_base.fb_in1k, ASR_fast.py:21-26) ----------------
+ * Depthwise k x k conv (groups = c), stride 1|2, padding k/2, NHWC; w_taps_c is the [c][1][k][k] weight transposed to
+ * [k*k][c] f32.  y is [b][ho][wo][c].                                                                          */
+int advs_dwconv2d(const void* x, const float* w_taps_c, const float* bias, void* y, int b, int h, int w, int c,
+                  int ksize, int stride, int dtype, void* stream);
+/* [b][h][w][c] -> [b][h/2][w/2][4c], channel (dy*2+dx)*c + ch: a Conv2d(c, cout, 2, stride 2) becomes a 1x1 conv. */
+int advs_space_to_depth2(const void* x, void* y, int b, int h, int w, int c, int dtype, void* stream);
+
 /* HF ViTForImageClassification victim (ASR_fast.py:47-51) token plumbing: image -> patch rows whose K order is
  * the patch-embedding conv weight's ([hidden][cin*ps*ps]); tokens = [cls | patches] + position embeddings, rows
  * padded with zeros to n_pad; CLS rows gathered to f32 for the classifier head.                                */

@@ -78,3 +78,22 @@ def hf_vit(num_labels=37, seed=2, **cfg):
     from transformers import ViTConfig, ViTForImageClassification
     torch.manual_seed(seed)
     return ViTForImageClassification(ViTConfig(num_labels=num_labels, **cfg)).eval()
+
+
+def hf_convnext(num_labels=37, seed=5, **cfg):
+    """The installed transformers ConvNextForImageClassification, random init (layer scale re-drawn so that it is
+    not the near-zero 1e-6 initial value, which would hide errors in the block bodies): the ConvNeXt victim's oracle.
+    The reference loads ``timm.create_model('convnext_base.fb_in1k')`` (ASR_fast.py:21-26); timm is absent, the
+    architecture is the same, the parameter names differ (the product maps them)."""
+    from transformers import ConvNextConfig, ConvNextForImageClassification
+    torch.manual_seed(seed)
+    m = ConvNextForImageClassification(ConvNextConfig(num_labels=num_labels, **cfg)).eval()
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if n.endswith("layer_scale_parameter"):
+                p.copy_(torch.rand_like(p) * 0.5 + 0.25)
+            elif "layernorm" in n or "downsampling_layer.0" in n:
+                p.copy_(torch.randn_like(p) * 0.1 + (1.0 if n.endswith("weight") else 0.0))
+            elif n.endswith("bias"):
+                p.copy_(torch.randn_like(p) * 0.05)
+    return m

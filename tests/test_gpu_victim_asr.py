@@ -153,3 +153,44 @@ def test_vgg16_matches_oracle():
     got = net(x.cuda()).cpu()
     assert (got - ref).abs().max().item() < 1e-3 * max(1.0, ref.abs().max().item())
     assert torch.equal(got.argmax(1), ref.argmax(1))
+
+
+# ------------------------------------------------------------------------------ ConvNeXt (ASR_fast.py:21-26)
+def test_convnext_small_config_matches_hf_transformers():
+    """A small ConvNeXt (depths 1-1-2-1, dims 64..512, 64 px) against the installed transformers implementation;
+    the HF parameter names are remapped to the timm names the reference's loader produces."""
+    from advshadow_amd.victims import ConvNeXtVictim
+    cfg = dict(depths=[1, 1, 2, 1], hidden_sizes=[64, 128, 256, 512], image_size=64)
+    hf = ov.hf_convnext(7, seed=5, **cfg)
+    x = torch.rand(3, 3, 64, 64, generator=torch.Generator().manual_seed(10))
+    with torch.no_grad():
+        ref = hf(pixel_values=x).logits
+    scale = max(1.0, ref.abs().max().item())
+    for dt, bound in (("fp32", 3e-4), ("fp16", 0.02), ("bf16", 0.08)):
+        net = ConvNeXtVictim(7, depths=cfg["depths"], dims=cfg["hidden_sizes"], image_size=64, head_norm_eps=1e-12, compute_dtype=dt)
+        net.load_state_dict(hf.state_dict())
+        net = net.to("cuda").eval()
+        for _ in range(2):
+            got = net(x.cuda()).cpu()
+            assert (got - ref).abs().max().item() < bound * scale, (dt, (got - ref).abs().max().item())
+        if dt == "fp32":
+            assert torch.equal(got.argmax(1), ref.argmax(1))
+    keys = set(net.state_dict().keys())
+    assert {"stem.0.weight", "stem.1.bias", "stages.1.downsample.1.weight", "stages.2.blocks.1.conv_dw.weight",
+            "stages.2.blocks.1.mlp.fc2.bias", "stages.0.blocks.0.gamma", "head.norm.weight", "head.fc.bias"} <= keys
+
+
+def test_convnext_base_top1_vs_hf():
+    """Full convnext_base geometry (depths 3-3-27-3, dims 128..1024, 224 px, 37 classes)."""
+    from advshadow_amd.victims import ConvNeXtVictim
+    hf = ov.hf_convnext(37, seed=6, depths=[3, 3, 27, 3], hidden_sizes=[128, 256, 512, 1024])
+    x = torch.rand(2, 3, 224, 224, generator=torch.Generator().manual_seed(11))
+    with torch.no_grad():
+        ref = hf(pixel_values=x).logits
+    net = ConvNeXtVictim(37, head_norm_eps=1e-12)
+    net.load_state_dict(hf.state_dict())
+    got = net.to("cuda").eval()(x.cuda()).cpu()
+    assert (got - ref).abs().max().item() < 1e-3 * max(1.0, ref.abs().max().item())
+    assert torch.equal(got.argmax(1), ref.argmax(1))
+    pred = asr.evaluate_batch((x * 255).to(torch.uint8).cuda(), net)           # plugs into the ASR path like any victim
+    assert pred.shape == (2,)
