@@ -57,6 +57,7 @@ SIGNATURES = {
     "advs_timestep_embedding": [vp, vp, i32, i32, vp, vp, vp, i32, vp],
     "advs_ddim_step": [vp, vp, vp, f32, vp, vp, vp, i32, vp, vp, i32, sz, i32, vp],
     "advs_ddpm_step": [vp, vp, vp, f32, vp, vp, vp, i32, vp, vp, i32, sz, vp],
+    "advs_ddpm_posterior_step": [vp, vp, vp, vp, vp, i32, vp, vp, i32, sz, i32, vp],
     "advs_plms_combine": [vp, vp, f32, vp, vp, vp, vp, i32, vp, vp, sz, vp],
     "advs_to_uint8": [vp, vp, sz, i32, vp],
     "advs_unit_to_uint8": [vp, vp, sz, vp],

@@ -237,6 +237,50 @@ extern "C" int advs_unit_to_uint8(const float* x, uint8_t* y, size_t n, void* st
     return ADVS_OK;
 }
 
+// ------------------------------------------------------------------ DDPM posterior step (diff_model.py:361-396)
+// GaussianDiffusion.p_sample: x_recon = clamp(sr[t] x - srm1[t] eps); mean = c1[t] x_recon + c2[t] x;
+// x <- mean + mask(t != 0) * exp(0.5 logvar[t]) * noise.  coef rows (per STEP, in loop order) hold
+// {sr, srm1, c1, c2, mask * exp(0.5 logvar)} as the host computed them with the reference's own f32 torch ops,
+// and the file is built with -ffp-contract=off: the result is bit-exact with the reference's op chain.
+__global__ void ddpm_posterior_step_kernel(float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ noise,
+                                           const float* __restrict__ coef, const int32_t* __restrict__ step_counter,
+                                           size_t n4, int clip) {
+    const int step = *step_counter;
+    const float sr = coef[5 * step], srm1 = coef[5 * step + 1], c1 = coef[5 * step + 2], c2 = coef[5 * step + 3],
+                sg = coef[5 * step + 4];
+    const f32x4* e4 = (const f32x4*)eps;
+    const f32x4* z4 = (const f32x4*)noise;
+    f32x4* x4 = (f32x4*)x;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 xv = x4[i], ev = e4[i], zv = z4[i];
+        f32x4 r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float x0 = sr * xv[j] - srm1 * ev[j];
+            if (clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+            const float mean = c1 * x0 + c2 * xv[j];
+            r[j] = mean + sg * zv[j];
+        }
+        x4[i] = r;
+    }
+}
+
+extern "C" int advs_ddpm_posterior_step(float* x, const float* eps, const float* noise, const float* coef,
+                                        const int64_t* tseq, int nsteps, int32_t* step_counter, int64_t* t_out,
+                                        int b, size_t per_sample, int clip, void* stream) {
+    ADVS_REQUIRE(x && eps && noise && coef && tseq && step_counter && t_out && b > 0 && per_sample > 0 && nsteps > 0,
+                 "ddpm_posterior_step: bad args");
+    const size_t n = (size_t)b * per_sample;
+    ADVS_REQUIRE(n % 4 == 0, "ddpm_posterior_step: element count %zu not a multiple of 4", n);
+    const size_t n4 = n / 4;
+    const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    ddpm_posterior_step_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, eps, noise, coef, step_counter, n4, clip);
+    ADVS_CHECK_LAUNCH("ddpm_posterior_step");
+    ddim_advance_kernel<<<1, 256, 0, (hipStream_t)stream>>>(step_counter, tseq, nsteps, t_out, b);
+    ADVS_CHECK_LAUNCH("ddim_advance");
+    return ADVS_OK;
+}
+
 // ------------------------------------------------------------------ DDPM ancestral update (model/samples/ddpm.py:86-88)
 //   eps' = lerp(eps_u, eps, cfg) (optional);  x = 1/sqrt(alpha) * (x - ((1-alpha)/sqrt(1-alpha_hat)) * eps') + sqrt(beta)*noise
 // coef[step] = {alpha, alpha_hat, beta}.  Same device-side step counter / timestep hand-off as advs_ddim_step.

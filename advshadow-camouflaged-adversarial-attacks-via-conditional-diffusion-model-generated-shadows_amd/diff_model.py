@@ -15,6 +15,7 @@ import math
 import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from . import _lib
 from .engine import BF16, F32, Builder, dtype_code, pack_conv_weight, ptr, SLAB_ELEMS
@@ -372,11 +373,115 @@ class GaussianDiffusion:
         self.betas = betas
         self.alphas = 1.0 - betas
         self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
+        # tables of the forward process and of the posterior q(x_{t-1} | x_t, x_0) (diff_model.py:304-331)
+        self.alphas_cumprod_prev = F.pad(self.alphas_cumprod[:-1], (1, 0), value=1.)
+        self.sqrt_alphas_cumprod = torch.sqrt(self.alphas_cumprod)
+        self.sqrt_one_minus_alphas_cumprod = torch.sqrt(1.0 - self.alphas_cumprod)
+        self.log_one_minus_alphas_cumprod = torch.log(1.0 - self.alphas_cumprod)
+        self.sqrt_recip_alphas_cumprod = torch.sqrt(1.0 / self.alphas_cumprod)
+        self.sqrt_recipm1_alphas_cumprod = torch.sqrt(1.0 / self.alphas_cumprod - 1)
+        self.posterior_variance = self.betas * (1.0 - self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
+        self.posterior_log_variance_clipped = torch.log(torch.cat([self.posterior_variance[1:2], self.posterior_variance[1:]]))
+        self.posterior_mean_coef1 = self.betas * torch.sqrt(self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
+        self.posterior_mean_coef2 = (1.0 - self.alphas_cumprod_prev) * torch.sqrt(self.alphas) / (1.0 - self.alphas_cumprod)
         self._loops = {}
+        self._ancestral = {}
 
     def _extract(self, a, t, x_shape):
         out = a.to(t.device).gather(0, t).float()
         return out.reshape(t.shape[0], *((1,) * (len(x_shape) - 1)))
+
+    # ---- forward process / posterior helpers: tiny elementwise torch ops on the caller's tensors, as in the reference
+    def q_sample(self, x_start, t, noise=None):
+        """diff_model.py:340-347."""
+        if noise is None:
+            noise = torch.randn_like(x_start)
+        return (self._extract(self.sqrt_alphas_cumprod, t, x_start.shape) * x_start
+                + self._extract(self.sqrt_one_minus_alphas_cumprod, t, x_start.shape) * noise)
+
+    def q_mean_variance(self, x_start, t):
+        """diff_model.py:349-353."""
+        return (self._extract(self.sqrt_alphas_cumprod, t, x_start.shape) * x_start,
+                self._extract(1.0 - self.alphas_cumprod, t, x_start.shape),
+                self._extract(self.log_one_minus_alphas_cumprod, t, x_start.shape))
+
+    def q_posterior_mean_variance(self, x_start, x_t, t):
+        """diff_model.py:356-363."""
+        mean = (self._extract(self.posterior_mean_coef1, t, x_t.shape) * x_start
+                + self._extract(self.posterior_mean_coef2, t, x_t.shape) * x_t)
+        return (mean, self._extract(self.posterior_variance, t, x_t.shape),
+                self._extract(self.posterior_log_variance_clipped, t, x_t.shape))
+
+    def predict_start_from_noise(self, x_t, t, noise):
+        """diff_model.py:366-370."""
+        return (self._extract(self.sqrt_recip_alphas_cumprod, t, x_t.shape) * x_t
+                - self._extract(self.sqrt_recipm1_alphas_cumprod, t, x_t.shape) * noise)
+
+    def p_mean_variance(self, model, x_t, t, clip_denoised=True):
+        """diff_model.py:373-383 (the eps-predictor runs on the HIP kernels; the rest is the reference's torch chain)."""
+        x_recon = self.predict_start_from_noise(x_t, t, model(x_t, t))
+        if clip_denoised:
+            x_recon = torch.clamp(x_recon, min=-1., max=1.)
+        return self.q_posterior_mean_variance(x_recon, x_t, t)
+
+    @torch.no_grad()
+    def p_sample(self, model, x_t, t, clip_denoised=True, noise=None):
+        """One ancestral step on caller tensors (diff_model.py:386-396); ``noise`` injects the randn_like."""
+        mean, _, logvar = self.p_mean_variance(model, x_t, t, clip_denoised=clip_denoised)
+        if noise is None:
+            noise = torch.randn_like(x_t)
+        mask = (t != 0).float().view(-1, *([1] * (len(x_t.shape) - 1)))
+        return mean + mask * (0.5 * logvar).exp() * noise
+
+    def _posterior_tables(self, device):
+        """[T][5] f32 per STEP in loop order (t = T-1 .. 0), rounded exactly where the reference rounds: f64 table ->
+        gather -> .float() (_extract), then f32 ops; the last column is mask * exp(0.5 * logvar)."""
+        order = torch.arange(self.timesteps - 1, -1, -1)
+        f = lambda a: a[order].float()
+        sg = (0.5 * f(self.posterior_log_variance_clipped)).exp() * (order != 0).float()
+        coef = torch.stack([f(self.sqrt_recip_alphas_cumprod), f(self.sqrt_recipm1_alphas_cumprod),
+                            f(self.posterior_mean_coef1), f(self.posterior_mean_coef2), sg], dim=1).contiguous()
+        return coef.to(device), order.to(torch.int64).to(device)
+
+    @torch.no_grad()
+    def p_sample_loop(self, model, shape, x_T=None, noise_fn=None, keep="all", clip_denoised=True):
+        """The full-length ancestral loop (diff_model.py:398-408): T x (eps-predictor forward + fused posterior step,
+        one captured graph replayed per step).  Returns the reference's list of per-step numpy images; extra
+        keywords (not in the reference): ``x_T`` / ``noise_fn(i, shape)`` inject the random stream, ``keep="last"``
+        skips the T-1 intermediate device->host copies and returns a one-element list."""
+        batch_size, channels, image_size = shape[0], shape[1], shape[2]
+        dev = next(model.parameters()).device
+        eng = model.engine(batch_size, image_size)
+        key = (id(eng), bool(clip_denoised))
+        loop = self._ancestral.get(key)
+        if loop is None:
+            coef, tseq = self._posterior_tables(dev)
+            loop = _AncestralLoop(eng, coef, tseq, clip_denoised)
+            self._ancestral = {key: loop}
+        cur = torch.cuda.current_stream(dev)
+        if x_T is None:
+            x_T = torch.randn(shape, device=dev)
+        eng.stream.wait_stream(cur)
+        imgs = []
+        with torch.cuda.stream(eng.stream):
+            eng.x.copy_(x_T.to(dev, torch.float32), non_blocking=True)
+            loop.start()
+            for i in reversed(range(self.timesteps)):
+                if noise_fn is not None:
+                    loop.noise.copy_(noise_fn(i, tuple(shape)).to(dev, torch.float32), non_blocking=True)
+                else:
+                    loop.noise.normal_()
+                loop.step()
+                if keep == "all" or i == 0:
+                    imgs.append(eng.x.to("cpu", non_blocking=True))
+        eng.stream.synchronize()
+        cur.wait_stream(eng.stream)
+        return [im.numpy() for im in imgs]
+
+    @torch.no_grad()
+    def sample(self, model, image_size, batch_size=8, channels=3, **kw):
+        """diff_model.py:411-413."""
+        return self.p_sample_loop(model, shape=(batch_size, channels, image_size, image_size), **kw)
 
     @staticmethod
     def ddim_sequences(timesteps, ddim_timesteps, method="uniform"):
@@ -433,6 +538,40 @@ class GaussianDiffusion:
         if return_tensor:
             return out
         return out.cpu().numpy()
+
+
+class _AncestralLoop:
+    """One captured step of GaussianDiffusion.p_sample: UNet forward + advs_ddpm_posterior_step."""
+
+    def __init__(self, eng, coef, tseq, clip):
+        self.eng, self.coef, self.tseq, self.nsteps = eng, coef, tseq, tseq.numel()
+        dev = eng.x.device
+        self.counter = torch.zeros((1,), dtype=torch.int32, device=dev)
+        self.noise = torch.zeros_like(eng.x)
+        from .engine import Plan
+        self.plan = Plan(eng.stream)
+        self.plan.ops = list(eng.plan.ops)
+        self.plan.keep = [eng.plan.keep, coef, tseq, self.counter, self.noise]
+        self.plan.add(_lib.load().advs_ddpm_posterior_step, ptr(eng.x), ptr(eng.eps), ptr(self.noise), ptr(coef), ptr(tseq),
+                      self.nsteps, ptr(self.counter), ptr(eng.t), eng.B, eng.x[0].numel(), 1 if clip else 0)
+        self.captured = False
+
+    def start(self):
+        eng = self.eng
+        self.counter.zero_()
+        eng.t.fill_(int(self.tseq[0].item()))
+        if eng.model.use_graph and not self.captured:
+            x0 = eng.x.clone()
+            self.plan.run_eager()
+            eng.stream.synchronize()
+            self.plan.capture()
+            self.captured = True
+            eng.x.copy_(x0)
+            self.counter.zero_()
+            eng.t.fill_(int(self.tseq[0].item()))
+
+    def step(self):
+        self.plan.run()
 
 
 class _DDIMLoop:

@@ -179,6 +179,15 @@ int advs_ddim_step(float* x, const float* eps, const float* eps_uncond, float cf
                    const float* noise, const float* coef, const int64_t* tseq, int nsteps,
                    int32_t* step_counter, int64_t* t_out, int b, size_t per_sample, int clip,
                    void* stream);
+/* GaussianDiffusion.p_sample (diff_model.py:361-396): the posterior step of the full-length ancestral sampler
+ * behind GaussianDiffusion.sample / p_sample_loop (what main.py:124 and gen.py:562 call).  coef is [nsteps][5] =
+ * {sqrt_recip_alphas_cumprod, sqrt_recipm1_alphas_cumprod, posterior_mean_coef1, posterior_mean_coef2,
+ *  (t != 0) * exp(0.5 * posterior_log_variance_clipped)} per step in loop order; the step counter, tseq and t_out
+ * work as in advs_ddim_step.  Bit-exact with the reference's f32 op chain.                                   */
+int advs_ddpm_posterior_step(float* x, const float* eps, const float* noise, const float* coef,
+                             const int64_t* tseq, int nsteps, int32_t* step_counter, int64_t* t_out,
+                             int b, size_t per_sample, int clip, void* stream);
+
 /* DDPM ancestral step (model/samples/ddpm.py:74-88): coef[step] = {alpha, alpha_hat, beta};
  *   x = 1/sqrt(alpha) * (x - ((1-alpha)/sqrt(1-alpha_hat)) * eps') + sqrt(beta) * noise (noise NULL = zeros). */
 int advs_ddpm_step(float* x, const float* eps, const float* eps_uncond, float cfg_scale, const float* noise,

@@ -281,3 +281,37 @@ def ddim_sample(model_fn, x_T, T=1000, schedule="cosine", steps=50, method="unif
         if trace is not None:
             trace.append((int(seq[i]), eps.clone(), x.clone()))
     return x.numpy()
+
+
+# --------------------------------------------------------------------------- full-length ancestral sampler
+def posterior_tables(T=1000, schedule="cosine"):
+    """The tables of GaussianDiffusion.__init__ that p_sample reads (diff_model.py:296-331), f64 like the reference."""
+    betas = betas_cosine(T) if schedule == "cosine" else betas_linear(T)
+    alphas = 1.0 - betas
+    ac = torch.cumprod(alphas, 0)
+    ac_prev = F.pad(ac[:-1], (1, 0), value=1.0)
+    pv = betas * (1.0 - ac_prev) / (1.0 - ac)
+    return dict(sqrt_recip=torch.sqrt(1.0 / ac), sqrt_recipm1=torch.sqrt(1.0 / ac - 1),
+                logvar=torch.log(torch.cat([pv[1:2], pv[1:]])),
+                c1=betas * torch.sqrt(ac_prev) / (1.0 - ac), c2=(1.0 - ac_prev) * torch.sqrt(alphas) / (1.0 - ac))
+
+
+@torch.no_grad()
+def p_sample_loop(model_fn, x_T, noises, T=1000, schedule="cosine", clip_denoised=True):
+    """GaussianDiffusion.p_sample_loop / p_sample / p_mean_variance (diff_model.py:361-408).  ``noises[i]`` is the
+    ``randn_like`` of step i (drawn for every step, multiplied by 0 at i == 0).  Returns the list of T images."""
+    tb = posterior_tables(T, schedule)
+    ex = lambda a, t: a.gather(0, t).float().reshape(-1, 1, 1, 1)           # _extract (diff_model.py:333-338)
+    img, out = x_T.clone(), []
+    B = img.shape[0]
+    for i in reversed(range(T)):
+        t = torch.full((B,), i, dtype=torch.long)
+        eps = model_fn(img, t)
+        x_recon = ex(tb["sqrt_recip"], t) * img - ex(tb["sqrt_recipm1"], t) * eps
+        if clip_denoised:
+            x_recon = torch.clamp(x_recon, min=-1.0, max=1.0)
+        mean = ex(tb["c1"], t) * x_recon + ex(tb["c2"], t) * img
+        mask = (t != 0).float().view(-1, 1, 1, 1)
+        img = mean + mask * (0.5 * ex(tb["logvar"], t)).exp() * noises[i]
+        out.append(img.clone())
+    return out

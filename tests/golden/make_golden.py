@@ -90,6 +90,22 @@ def gen_lineage_b():
 
     small = dict(model_channels=64, channel_mult=(1, 2), num_res_blocks=1, attention_resolutions=(2,), num_heads=4)
     run("small", 3, small, 32, 2, [1, 501, 981], 5)
+    # GaussianDiffusion.sample = the full-length ancestral loop (what main.py:124 / gen.py:562 call), here with
+    # timesteps=24 so that the CPU suite can replay it: RNG stream = x_T, then one randn_like per step
+    torch.manual_seed(3)
+    net = dm.UNetModel(**small).eval()
+    arrs = {}
+    for sched in ("cosine", "linear"):
+        gd = dm.GaussianDiffusion(timesteps=24, beta_schedule=sched)
+        torch.manual_seed(4242)
+        xT = torch.randn((2, 3, 32, 32))
+        noise = np.stack([torch.randn((2, 3, 32, 32)).numpy() for _ in range(24)])           # steps 23, 22, ..., 0
+        torch.manual_seed(4242)
+        imgs = gd.sample(net, 32, batch_size=2, channels=3)
+        arrs["xT"], arrs["noise"] = xT.numpy(), noise                  # same seed: identical stream for both schedules
+        arrs[f"imgs_{sched}"] = np.stack([imgs[k] for k in (0, 11, 22, 23)])
+        arrs[f"len_{sched}"] = np.array(len(imgs))
+    save("lineage_b_ancestral.npz", **arrs)
     # attention at two levels + three res blocks + no-attention level, odd head count
     mid = dict(model_channels=64, channel_mult=(1, 2, 3), num_res_blocks=2, attention_resolutions=(1, 4), num_heads=2)
     run("mid", 5, mid, 32, 1, [21, 741], 4)

@@ -64,3 +64,16 @@ def test_ddim_loop_matches_reference(golden, tag, sched):
     ref = g[f"ddim_out_{sched}"]
     assert out.dtype == np.float32 and out.shape == ref.shape
     assert np.abs(out - ref).max() < 1e-4
+
+
+@pytest.mark.parametrize("sched", ["cosine", "linear"])
+def test_ancestral_loop_matches_reference(golden, sched):
+    """GaussianDiffusion.sample (p_sample_loop, diff_model.py:398-413) with timesteps=24: every recorded step."""
+    g = golden("lineage_b_ancestral.npz")
+    hp = ob.hparams(model_channels=64, channel_mult=(1, 2), num_res_blocks=1, attention_resolutions=(2,), num_heads=4)
+    sd = ob.init_state_dict(3, hp)
+    noises = {23 - k: torch.from_numpy(g["noise"][k]) for k in range(24)}
+    imgs = ob.p_sample_loop(lambda x, t: ob.unet_forward(sd, hp, x, t), torch.from_numpy(g["xT"]), noises, T=24, schedule=sched)
+    assert len(imgs) == int(g[f"len_{sched}"]) == 24
+    for j, k in enumerate((0, 11, 22, 23)):
+        assert np.abs(imgs[k].numpy() - g[f"imgs_{sched}"][j]).max() < 2e-5, k
