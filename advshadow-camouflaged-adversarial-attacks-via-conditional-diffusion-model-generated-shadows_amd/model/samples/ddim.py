@@ -8,6 +8,8 @@ Extra keywords: ``x_T`` (inject the start noise; otherwise drawn with torch's CP
 moved to the device exactly as ddim.py:62 does), ``clamp`` (saturate instead of wrapping),
 ``return_float`` (skip the uint8 cast).
 """
+import math
+
 import torch
 
 from ... import _lib
@@ -21,9 +23,33 @@ class BaseDiffusion:
         self.noise_steps, self.beta_start, self.beta_end = noise_steps, beta_start, beta_end
         self.img_size, self.device = img_size, device
         # computed on the host so the fp32 cumprod is identical on every device
-        self.beta = torch.linspace(beta_start, beta_end, noise_steps)
+        self.beta = self.prepare_noise_schedule()
         self.alpha = 1.0 - self.beta
         self.alpha_hat = torch.cumprod(self.alpha, dim=0)
+
+    def prepare_noise_schedule(self, schedule_name="linear"):
+        """model/samples/base.py:40-85 (the constructor always takes "linear", base.py:34)."""
+        if schedule_name == "linear":
+            return torch.linspace(self.beta_start, self.beta_end, self.noise_steps)
+        if schedule_name == "cosine":
+            f = lambda t: math.cos((t + 0.008) / 1.008 * math.pi / 2) ** 2
+            n = self.noise_steps
+            return torch.tensor([min(1 - f((i + 1) / n) / f(i / n), 0.999) for i in range(n)])
+        if schedule_name == "sqrt_linear":
+            return torch.linspace(self.beta_start ** 0.5, self.beta_end ** 0.5, self.noise_steps) ** 2
+        if schedule_name == "sqrt":
+            return torch.linspace(self.beta_start, self.beta_end, self.noise_steps) ** 0.5
+        raise NotImplementedError(f"Unknown beta schedule: {schedule_name}")
+
+    def noise_images(self, x, time):
+        """model/samples/base.py:86-98: (sqrt(a_hat) x + sqrt(1 - a_hat) eps, eps) on x's device."""
+        ah = self.alpha_hat.to(x.device)[time]
+        eps = torch.randn_like(x)
+        return torch.sqrt(ah)[:, None, None, None] * x + torch.sqrt(1 - ah)[:, None, None, None] * eps, eps
+
+    def sample_time_steps(self, n):
+        """model/samples/base.py:100-108."""
+        return torch.randint(low=1, high=self.noise_steps, size=(n,))
 
 
 class DDIMDiffusion(BaseDiffusion):

@@ -152,7 +152,8 @@ def gen_lineage_a():
     run("gelu", 2, "gelu", False)
     d500 = DDIMDiffusion(img_size=64, device="cpu")                # defaults: 500 sample steps
     save("lineage_a_schedule.npz", alpha_hat=d500.alpha_hat.numpy(),
-         time_pairs_500=np.array([[int(a), int(b)] for a, b in d500.time_step]))
+         time_pairs_500=np.array([[int(a), int(b)] for a, b in d500.time_step]),
+         **{f"beta_{n}": d500.prepare_noise_schedule(n).numpy() for n in ("linear", "cosine", "sqrt_linear", "sqrt")})
 
 
 # --------------------------------------------------------------------------- DDPM / PLMS samplers
