@@ -104,15 +104,22 @@ gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ x2, int C1, const
             s_mean[g] = meanrstd[((size_t)b * G + g) * 2];
             s_rstd[g] = meanrstd[((size_t)b * G + g) * 2 + 1];
         }
-    } else
-    for (int g = tid; g < G; g += GN_THREADS) {
+    } else {
+        // 4 lanes per group walk the chunk partials (fixed interleave), then fold: G <= 64 groups x 4 = 256 threads
+        const int g = tid >> 2, sub = tid & 3;
         double a = 0.0, d = 0.0;
-        const float* p = partials + ((size_t)b * nchunk * G + g) * 2;
-        for (int k = 0; k < nchunk; ++k) { a += (double)p[(size_t)k * G * 2]; d += (double)p[(size_t)k * G * 2 + 1]; }
-        double n = (double)HW * cpg, mean = a / n, var = d / n - mean * mean;
-        if (var < 0.0) var = 0.0;
-        s_mean[g] = (float)mean;
-        s_rstd[g] = (float)(1.0 / sqrt(var + 1e-5));
+        if (g < G) {
+            const float* p = partials + ((size_t)b * nchunk * G + g) * 2;
+            for (int k = sub; k < nchunk; k += 4) { a += (double)p[(size_t)k * G * 2]; d += (double)p[(size_t)k * G * 2 + 1]; }
+        }
+        a += __shfl_xor(a, 1); d += __shfl_xor(d, 1);
+        a += __shfl_xor(a, 2); d += __shfl_xor(d, 2);
+        if (g < G && sub == 0) {
+            double n = (double)HW * cpg, mean = a / n, var = d / n - mean * mean;
+            if (var < 0.0) var = 0.0;
+            s_mean[g] = (float)mean;
+            s_rstd[g] = (float)(1.0 / sqrt(var + 1e-5));
+        }
     }
     __syncthreads();
     const int pl = tid / vpp, cv = tid - pl * vpp;
@@ -234,15 +241,18 @@ static int gn_launch(const void* x, const void* x2, int c1, const float* gamma, 
     int nchunk = 1;
     if (st1) {
         const int rbmax = rbpi1 > rbpi2 ? rbpi1 : rbpi2;
-        nchunk = 256 / b;                                   // enough workgroups to cover the chip
+        // a FIXED number of chunks (not a function of the batch): the rounding points of the per-chunk f32 partials,
+        // and with them the statistics of an image, do not depend on which batch the image is evaluated in.
+        // 32 x batch workgroups: the fold is latency-bound, a full-size batch fills the chip four times over.
+        nchunk = 32;
         if (nchunk > rbmax / 8) nchunk = rbmax / 8;
         if (nchunk > GN_MAX_CHUNKS) nchunk = GN_MAX_CHUNKS;
         if (nchunk < 1) nchunk = 1;
         gn_stats_fold_kernel<<<dim3(nchunk, b), 256, 0, st>>>(st1, rbpi1, c1, st2, rbpi2, c - c1, partials, groups, nchunk);
         ADVS_CHECK_LAUNCH("gn_stats_fold");
     } else {
-    // enough chunks to fill 256 CUs several times over, but >= 4 pixels per lane per chunk
-    nchunk = 2048 / b;
+    // a fixed chunk count (batch-independent rounding points, see above), >= 4 pixels per lane per chunk
+    nchunk = 64;
     int maxc = hw / (PIXB * 4);
     if (nchunk > maxc) nchunk = maxc;
     if (nchunk > GN_MAX_CHUNKS) nchunk = GN_MAX_CHUNKS;
