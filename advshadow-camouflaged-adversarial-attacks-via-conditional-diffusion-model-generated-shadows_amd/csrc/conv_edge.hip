@@ -185,6 +185,7 @@ conv_first_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
 // Pixels per statistics block of the MFMA first conv for this shape, or 0 when that path (or its statistics)
 // does not apply: 16-bit dtype, 9 * cin <= 32, cout 64 or 128, w a multiple of 16, h * w a multiple of 1024.
 extern "C" int advs_conv_first_stats_rows(int cin, int h, int w, int cout, int dtype) {
+    ADVS_REQUIRE(dtype_ok(dtype), "advs_conv_first_stats_rows: unknown dtype code %d", dtype);
     if (dtype == ADVS_F32 || cin < 1 || cin * 9 > 32 || (cout != 64 && cout != 128) || w % 16) return 0;
     return ((long long)h * w) % (16 * FS_TILES) == 0 ? 16 * FS_TILES : 0;
 }
@@ -205,6 +206,7 @@ static int conv_first_mfma_launch(const float* x, const float* w, const float* b
 
 extern "C" int advs_conv3x3_first_stats(const float* x, const float* w, const float* bias, void* y, float* stats,
                                         int b, int cin, int h, int wd, int cout, int dtype, void* stream) {
+    ADVS_REQUIRE(dtype_ok(dtype), "advs_conv3x3_first_stats: unknown dtype code %d", dtype);
     ADVS_REQUIRE(x && w && y && b > 0 && h > 0 && wd > 0, "conv3x3_first: bad args");
     ADVS_REQUIRE(cin >= 1 && cin <= 4, "conv3x3_first: cin=%d must be <= 4", cin);
     ADVS_REQUIRE(cout % 8 == 0 && cout <= 512, "conv3x3_first: cout=%d must be a multiple of 8, <= 512", cout);
@@ -226,6 +228,7 @@ extern "C" int advs_conv3x3_first_stats(const float* x, const float* w, const fl
 
 extern "C" int advs_conv3x3_first(const float* x, const float* w, const float* bias, void* y,
                                   int b, int cin, int h, int wd, int cout, int dtype, void* stream) {
+    ADVS_REQUIRE(dtype_ok(dtype), "advs_conv3x3_first: unknown dtype code %d", dtype);
     return advs_conv3x3_first_stats(x, w, bias, y, nullptr, b, cin, h, wd, cout, dtype, stream);
 }
 
@@ -629,6 +632,7 @@ static int conv_last16_launch(const void* x, const float* w, const float* bias, 
 
 extern "C" int advs_conv_last(const void* x, const float* w, const float* bias, float* y,
                               int b, int cin, int h, int wd, int cout, int ksize, int dtype, void* stream) {
+    ADVS_REQUIRE(dtype_ok(dtype), "advs_conv_last: unknown dtype code %d", dtype);
     ADVS_REQUIRE(x && w && y && b > 0 && h > 0 && wd > 0, "conv_last: bad args");
     ADVS_REQUIRE(cout >= 1 && cout <= 4, "conv_last: cout=%d must be <= 4", cout);
     ADVS_REQUIRE(ksize == 1 || ksize == 3, "conv_last: ksize %d unsupported", ksize);

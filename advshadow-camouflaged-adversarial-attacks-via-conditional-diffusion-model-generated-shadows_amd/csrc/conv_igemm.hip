@@ -366,6 +366,7 @@ extern "C" int advs_conv_tile_rows(int tile) {
 
 extern "C" int advs_conv2d(const advs_conv_args* a, void* stream) {
     ADVS_REQUIRE(a && a->x1 && a->w && a->y, "conv2d: null pointer");
+    ADVS_REQUIRE(dtype_ok(a->dtype), "conv2d: unknown dtype code %d", a->dtype);
     ADVS_REQUIRE(a->b > 0 && a->h > 0 && a->w_ > 0 && a->c1 > 0 && a->c2 >= 0 && a->cout > 0, "conv2d: bad shape");
     ADVS_REQUIRE(a->ksize == 1 || a->ksize == 3, "conv2d: ksize %d unsupported", a->ksize);
     ADVS_REQUIRE(a->stride == 1 || a->stride == 2, "conv2d: stride %d unsupported", a->stride);

@@ -19,6 +19,7 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, T* __restri
 
 extern "C" int advs_pack_conv_weight(const float* w, void* out, int cout, int cin, int r, int s,
                                      int dtype, void* stream) {
+    ADVS_REQUIRE(dtype_ok(dtype), "advs_pack_conv_weight: unknown dtype code %d", dtype);
     ADVS_REQUIRE(w && out && cout > 0 && cin > 0 && r > 0 && s > 0, "pack_conv_weight: bad args");
     size_t total = (size_t)cout * cin * r * s;
     int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
@@ -63,6 +64,7 @@ __global__ void layout_kernel(const void* __restrict__ src, void* __restrict__ d
 }
 
 extern "C" int advs_nchw_f32_to_nhwc(const float* x, void* y, int b, int c, int h, int w, int dtype, void* stream) {
+    ADVS_REQUIRE(dtype_ok(dtype), "advs_nchw_f32_to_nhwc: unknown dtype code %d", dtype);
     ADVS_REQUIRE(x && y && b > 0 && c > 0 && h > 0 && w > 0, "nchw_to_nhwc: bad args");
     dim3 grid(cdiv((long long)h * w, 32), cdiv(c, 32), b);
     ADVS_SWITCH_T(dtype, layout_kernel<T, true><<<grid, 256, 0, (hipStream_t)stream>>>(x, y, c, h * w));
@@ -70,6 +72,7 @@ extern "C" int advs_nchw_f32_to_nhwc(const float* x, void* y, int b, int c, int 
     return ADVS_OK;
 }
 extern "C" int advs_nhwc_to_nchw_f32(const void* x, float* y, int b, int c, int h, int w, int dtype, void* stream) {
+    ADVS_REQUIRE(dtype_ok(dtype), "advs_nhwc_to_nchw_f32: unknown dtype code %d", dtype);
     ADVS_REQUIRE(x && y && b > 0 && c > 0 && h > 0 && w > 0, "nhwc_to_nchw: bad args");
     dim3 grid(cdiv((long long)h * w, 32), cdiv(c, 32), b);
     ADVS_SWITCH_T(dtype, layout_kernel<T, false><<<grid, 256, 0, (hipStream_t)stream>>>(x, y, c, h * w));

@@ -276,6 +276,7 @@ extern "C" int advs_groupnorm(const void* x, const void* x2, const float* gamma,
                               const void* residual_in, const float* chan_add, int chan_add_stride, void* y,
                               void* partials, int b, int hw, int c1, int c2, int groups, int act, int dtype,
                               void* stream) {
+    ADVS_REQUIRE(dtype_ok(dtype), "advs_groupnorm: unknown dtype code %d", dtype);
     ADVS_REQUIRE(x && gamma && beta && y && partials, "groupnorm: null pointer");
     ADVS_REQUIRE(c1 > 0 && c2 >= 0 && (c2 == 0) == (x2 == nullptr), "groupnorm: x2/c2 mismatch");
     const int c = c1 + c2;
@@ -295,6 +296,7 @@ extern "C" int advs_groupnorm_stats(const void* x, const void* x2, const float* 
                                     const float* beta, const void* residual_in, const float* chan_add,
                                     int chan_add_stride, void* y, void* scratch, int b, int hw, int c1, int c2,
                                     int groups, int act, int dtype, void* stream) {
+    ADVS_REQUIRE(dtype_ok(dtype), "advs_groupnorm_stats: unknown dtype code %d", dtype);
     ADVS_REQUIRE(x && gamma && beta && y && scratch && stats1 && row_blocks_per_image1 > 0, "groupnorm_stats: null pointer");
     ADVS_REQUIRE(c1 > 0 && c2 >= 0 && (c2 == 0) == (x2 == nullptr) && (c2 == 0) == (stats2 == nullptr),
                  "groupnorm_stats: x2/c2/stats2 mismatch");

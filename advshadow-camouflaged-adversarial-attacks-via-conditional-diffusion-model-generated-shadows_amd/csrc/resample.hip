@@ -34,6 +34,7 @@ __global__ void maxpool2_kernel(const T* __restrict__ x, T* __restrict__ y, int 
 }
 
 extern "C" int advs_maxpool2(const void* x, void* y, int b, int h, int w, int c, int dtype, void* stream) {
+    ADVS_REQUIRE(dtype_ok(dtype), "advs_maxpool2: unknown dtype code %d", dtype);
     ADVS_REQUIRE(x && y && b > 0 && h > 1 && w > 1 && h % 2 == 0 && w % 2 == 0, "maxpool2: bad shape");
     const int vec = dtype == ADVS_F32 ? 4 : 8;
     ADVS_REQUIRE(c % vec == 0, "maxpool2: c=%d must be a multiple of %d", c, vec);
@@ -103,10 +104,12 @@ static int concat_up_launch(const char* name, const void* skip, const void* x, v
 
 extern "C" int advs_concat_upsample2x(const void* skip, const void* x, void* y, int b, int h, int w, int c1, int c2,
                                       int dtype, void* stream) {
+    ADVS_REQUIRE(dtype_ok(dtype), "advs_concat_upsample2x: unknown dtype code %d", dtype);
     return concat_up_launch<false>("concat_upsample2x", skip, x, y, b, h, w, c1, c2, dtype, stream);
 }
 extern "C" int advs_concat_nearest2x(const void* skip, const void* x, void* y, int b, int h, int w, int c1, int c2,
                                      int dtype, void* stream) {
+    ADVS_REQUIRE(dtype_ok(dtype), "advs_concat_nearest2x: unknown dtype code %d", dtype);
     return concat_up_launch<true>("concat_nearest2x", skip, x, y, b, h, w, c1, c2, dtype, stream);
 }
 
@@ -161,6 +164,7 @@ layernorm_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const
 
 extern "C" int advs_layernorm(const void* x, const float* gamma, const float* beta, void* y, long long rows, int c,
                               float eps, int dtype, void* stream) {
+    ADVS_REQUIRE(dtype_ok(dtype), "advs_layernorm: unknown dtype code %d", dtype);
     ADVS_REQUIRE(x && gamma && beta && y && rows > 0 && c > 0, "layernorm: bad args");
     const int vec = dtype == ADVS_F32 ? 4 : 8;
     ADVS_REQUIRE(c % vec == 0, "layernorm: c=%d must be a multiple of %d", c, vec);

@@ -57,6 +57,7 @@ conv_stem_kernel(const float* __restrict__ x, const float* __restrict__ w, const
 extern "C" int advs_conv_stem(const float* x_nchw, const float* w_oihw, const float* bias, void* y,
                               int b, int cin, int h, int w, int cout, int ksize, int stride, int pad, int act,
                               int dtype, void* stream) {
+    ADVS_REQUIRE(dtype_ok(dtype), "advs_conv_stem: unknown dtype code %d", dtype);
     ADVS_REQUIRE(x_nchw && w_oihw && y && b > 0 && h > 0 && w > 0, "conv_stem: bad args");
     ADVS_REQUIRE(cin >= 1 && cin <= 4 && cout % 32 == 0 && ksize >= 1 && ksize <= 7 && stride >= 1 && pad >= 0,
                  "conv_stem: unsupported shape cin=%d cout=%d k=%d", cin, cout, ksize);
@@ -104,6 +105,7 @@ __global__ void maxpool3s2_kernel(const T* __restrict__ x, T* __restrict__ y, in
 }
 
 extern "C" int advs_maxpool3x3s2(const void* x, void* y, int b, int h, int w, int c, int dtype, void* stream) {
+    ADVS_REQUIRE(dtype_ok(dtype), "advs_maxpool3x3s2: unknown dtype code %d", dtype);
     ADVS_REQUIRE(x && y && b > 0 && h > 0 && w > 0, "maxpool3x3s2: bad args");
     const int vec = dtype == ADVS_F32 ? 4 : 8;
     ADVS_REQUIRE(c % vec == 0, "maxpool3x3s2: c=%d must be a multiple of %d", c, vec);
@@ -131,6 +133,7 @@ global_avgpool_kernel(const T* __restrict__ x, float* __restrict__ y, int HW, in
 }
 
 extern "C" int advs_global_avgpool(const void* x, float* y, int b, int hw, int c, int dtype, void* stream) {
+    ADVS_REQUIRE(dtype_ok(dtype), "advs_global_avgpool: unknown dtype code %d", dtype);
     ADVS_REQUIRE(x && y && b > 0 && hw > 0 && c > 0, "global_avgpool: bad args");
     dim3 grid(cdiv(c, 64), b);
     ADVS_SWITCH_T(dtype, global_avgpool_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T*)x, y, hw, c));
@@ -157,6 +160,7 @@ __global__ void patchify_kernel(const float* __restrict__ x, T* __restrict__ y, 
     }
 }
 extern "C" int advs_patchify(const float* x_nchw, void* y, int b, int cin, int h, int w, int patch, int dtype, void* stream) {
+    ADVS_REQUIRE(dtype_ok(dtype), "advs_patchify: unknown dtype code %d", dtype);
     ADVS_REQUIRE(x_nchw && y && b > 0 && cin > 0 && patch > 0 && h % patch == 0 && w % patch == 0, "patchify: bad args");
     const size_t total = (size_t)b * cin * h * w;
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
@@ -184,6 +188,7 @@ __global__ void vit_assemble_kernel(const T* __restrict__ patches, const float* 
 }
 extern "C" int advs_vit_assemble(const void* patches, const float* cls, const float* pos, void* tokens, int b, int np,
                                  int n_pad, int c, int dtype, void* stream) {
+    ADVS_REQUIRE(dtype_ok(dtype), "advs_vit_assemble: unknown dtype code %d", dtype);
     ADVS_REQUIRE(patches && cls && pos && tokens && b > 0 && np > 0 && n_pad > np && c > 0, "vit_assemble: bad args");
     const size_t total = (size_t)b * n_pad * c;
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
@@ -201,6 +206,7 @@ __global__ void gather_rows_kernel(const T* __restrict__ x, float* __restrict__ 
     y[i] = Elt<T>::ld(x + (size_t)b * row_stride * C + c);
 }
 extern "C" int advs_gather_rows_f32(const void* x, float* y, int b, long long row_stride, int c, int dtype, void* stream) {
+    ADVS_REQUIRE(dtype_ok(dtype), "advs_gather_rows_f32: unknown dtype code %d", dtype);
     ADVS_REQUIRE(x && y && b > 0 && c > 0 && row_stride > 0, "gather_rows_f32: bad args");
     ADVS_SWITCH_T(dtype, gather_rows_kernel<T><<<cdiv((long long)b * c, 256), 256, 0, (hipStream_t)stream>>>((const T*)x, y, b, row_stride, c));
     ADVS_CHECK_LAUNCH("gather_rows_f32");
@@ -248,6 +254,7 @@ dwconv_kernel(const T* __restrict__ x, const float* __restrict__ w, const float*
 
 extern "C" int advs_dwconv2d(const void* x, const float* w_taps_c, const float* bias, void* y, int b, int h, int w, int c,
                              int ksize, int stride, int dtype, void* stream) {
+    ADVS_REQUIRE(dtype_ok(dtype), "advs_dwconv2d: unknown dtype code %d", dtype);
     ADVS_REQUIRE(x && w_taps_c && y && b > 0 && h > 0 && w > 0 && c > 0, "dwconv2d: bad args");
     ADVS_REQUIRE((ksize & 1) && ksize >= 1 && ksize <= 7 && (stride == 1 || stride == 2), "dwconv2d: ksize %d / stride %d unsupported", ksize, stride);
     const int vec = dtype == ADVS_F32 ? 4 : 8;
@@ -280,6 +287,7 @@ __global__ void space_to_depth2_kernel(const T* __restrict__ x, T* __restrict__ 
 }
 
 extern "C" int advs_space_to_depth2(const void* x, void* y, int b, int h, int w, int c, int dtype, void* stream) {
+    ADVS_REQUIRE(dtype_ok(dtype), "advs_space_to_depth2: unknown dtype code %d", dtype);
     ADVS_REQUIRE(x && y && b > 0 && h > 0 && w > 0 && h % 2 == 0 && w % 2 == 0, "space_to_depth2: bad shape");
     const int vec = dtype == ADVS_F32 ? 4 : 8;
     ADVS_REQUIRE(c % vec == 0, "space_to_depth2: c=%d must be a multiple of %d", c, vec);

@@ -520,3 +520,19 @@ def test_groupnorm_residual_after_activation(dt):
     op.go()
     err = (nchw(y) - ref).abs().max().item()
     assert err < tol(dt, 2e-5, 6e-2), err
+
+
+def test_unknown_dtype_code_is_rejected():
+    """Every entry point that takes a dtype code refuses one it does not know (no silent f32 interpretation)."""
+    lib = _lib.load()
+    _lib.init_device()
+    x = torch.zeros(1, 8, 8, 64, device=dev())
+    y = torch.zeros_like(x)
+    rc = lib.advs_maxpool2(x.data_ptr(), y.data_ptr(), 1, 8, 8, 64, 7, torch.cuda.current_stream().cuda_stream)
+    assert rc != 0 and "unknown dtype" in lib.advs_last_error().decode()
+    op = OneOp("fp32", 1)
+    w = pack_conv_weight(torch.zeros(64, 64, 1, 1, device=dev()), dtype_code("fp32"))
+    op.b.conv(x, w, 64, ksize=1, pad=0)
+    fn, args = op.b.plan.ops[-1]
+    args[0]._obj.dtype = 9
+    assert fn(*args, op.stream.cuda_stream) != 0 and "unknown dtype" in lib.advs_last_error().decode()
