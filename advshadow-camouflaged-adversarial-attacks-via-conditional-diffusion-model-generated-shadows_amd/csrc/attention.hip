@@ -33,7 +33,7 @@ attn_kernel(const AttnP p) {
     constexpr int VEC = 16 / ESZ;
     constexpr int DMAX = DT * 32;
     constexpr int KS = DMAX * ESZ + 16;           // K tile row stride (bytes), padded
-    constexpr int VS = KT * ESZ + 16;             // V^T tile row stride (bytes), padded
+    constexpr int VS = KT * ESZ + (ESZ == 2 ? 8 : 16);   // V^T tile row stride (bytes): 34 / 68 dwords spread the rows over the banks
     constexpr int QSTEPS = DMAX * ESZ / 32;       // max 32-byte k-steps over d
     extern __shared__ __attribute__((aligned(16))) char sm[];     // KT*KS + DMAX*VS bytes
     char* sK = sm;
@@ -72,28 +72,70 @@ attn_kernel(const AttnP p) {
     const int cprp = dsteps * 2;                  // ... of the K tile incl. the zero half step
     const int nvec = KT * cprp;
 
-    for (int k0 = 0; k0 < p.n_valid; k0 += KT) {
-        __syncthreads();                          // previous tile fully consumed
-        for (int v = tid; v < nvec; v += AT_THREADS) {
+    // The next tile's K / V vectors travel in registers while the current tile is being consumed: the global
+    // latency hides behind the MFMAs instead of sitting between two barriers.
+    // K: one 16-byte vector per (key, chunk), stored as it comes.  V: a thread takes FOUR consecutive keys of one
+    // chunk and writes them transposed, 4 keys (8 or 16 bytes) per V^T row at a time -- the per-element transposing
+    // stores of a single key were 16-way bank conflicted (every chunk's rows start on the same bank).
+    constexpr int NV = DMAX * ESZ / 64;           // K vectors per thread per tile (upper bound)
+    constexpr int NQ = (DMAX * ESZ + 255) / 256;  // V key-quads per thread per tile: 16 quads x (d*ESZ/16) chunks / 256
+    u32x4 kreg[NV], vreg[NQ][4];
+    const int nquad = (KT / 4) * cpr;
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = tid + i * AT_THREADS;
+            kreg[i] = u32x4{0, 0, 0, 0};
+            if (v < nvec) {
+                const int key = v / cprp, ch = v - key * cprp;
+                if (ch < cpr && k0 + key < p.N) kreg[i] = *(const u32x4*)(kp + (size_t)(k0 + key) * rowb + ch * 16);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int v = tid + i * AT_THREADS;
+            const int kq = v / cpr, ch = v - kq * cpr;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int key = k0 + 4 * kq + j;      // the last tile of a short sequence (N = 16 at 4x4) is zero-filled
+                vreg[i][j] = (v < nquad && key < p.N) ? *(const u32x4*)(vp + (size_t)key * rowb + ch * 16) : u32x4{0, 0, 0, 0};
+            }
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = tid + i * AT_THREADS;
+            if (v >= nvec) continue;
             const int key = v / cprp, ch = v - key * cprp;
-            const size_t g = (size_t)(k0 + key) * rowb + ch * 16;
-            if (ch >= cpr) { *(u32x4*)(sK + key * KS + ch * 16) = u32x4{0, 0, 0, 0}; continue; }
-            const bool in = k0 + key < p.N;           // the last tile of a short sequence (N = 16 at 4x4) is zero-filled
-            const u32x4 kv = in ? *(const u32x4*)(kp + g) : u32x4{0, 0, 0, 0};
-            const u32x4 vv = in ? *(const u32x4*)(vp + g) : u32x4{0, 0, 0, 0};
-            *(u32x4*)(sK + key * KS + ch * 16) = kv;
+            *(u32x4*)(sK + key * KS + ch * 16) = kreg[i];          // chunks >= cpr: the zero half step
+        }
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int v = tid + i * AT_THREADS;
+            if (v >= nquad) continue;
+            const int kq = v / cpr, ch = v - kq * cpr;
             if (ESZ == 2) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    unsigned short h = (unsigned short)((vv[e >> 1] >> ((e & 1) * 16)) & 0xffff);
-                    *(unsigned short*)(sV + (ch * 8 + e) * VS + key * 2) = h;
+                for (int e = 0; e < 8; ++e) {                      // row d = 8 ch + e gets keys 4kq .. 4kq+3 (8 bytes)
+                    const int w = e >> 1, sh = (e & 1) * 16;
+                    const unsigned k01 = ((vreg[i][0][w] >> sh) & 0xffffu) | (((vreg[i][1][w] >> sh) & 0xffffu) << 16);
+                    const unsigned k23 = ((vreg[i][2][w] >> sh) & 0xffffu) | (((vreg[i][3][w] >> sh) & 0xffffu) << 16);
+                    *(u32x2*)(sV + (ch * 8 + e) * VS + kq * 8) = u32x2{k01, k23};
                 }
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) *(unsigned*)(sV + (ch * 4 + e) * VS + key * 4) = vv[e];
+                for (int e = 0; e < 4; ++e)
+                    *(u32x4*)(sV + (ch * 4 + e) * VS + kq * 16) = u32x4{vreg[i][0][e], vreg[i][1][e], vreg[i][2][e], vreg[i][3][e]};
             }
         }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < p.n_valid; k0 += KT) {
+        __syncthreads();                          // previous tile fully consumed
+        commit();
         __syncthreads();
+        if (k0 + KT < p.n_valid) fetch(k0 + KT);
         if (!active) continue;
 
         // ---- S^T = K Q^T for the two 32-key blocks
@@ -118,23 +160,31 @@ attn_kernel(const AttnP p) {
             }
         }
         // ---- online softmax over this tile's 64 keys (32 in this lane, 32 in lane^32)
-        float mx = -INFINITY;
+        if (k0 + KT > p.n_valid) {                          // only the last tile can hold padded keys (wave-uniform)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (key >= p.n_valid) st[kb][r] = -INFINITY;
+                }
+        }
+        float mx = -INFINITY;                               // max of the RAW scores; the scale (> 0) is applied once
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                st[kb][r] = key < p.n_valid ? st[kb][r] * p.scale_log2e : -INFINITY;
-                mx = fmaxf(mx, st[kb][r]);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kb][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32)) * p.scale_log2e;
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = exp2f(m_run - m_new);          // exp2(-inf) = 0 on the first tile
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);       // exp2(-inf) = 0 on the first tile
         float ls = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { st[kb][r] = exp2f(st[kb][r] - m_new); ls += st[kb][r]; }
+            for (int r = 0; r < 16; ++r) {                  // one FMA + one v_exp_f32 per score
+                st[kb][r] = __builtin_amdgcn_exp2f(fmaf(st[kb][r], p.scale_log2e, -m_new));
+                ls += st[kb][r];
+            }
         l_run = l_run * alpha + ls;
         m_run = m_new;
 #pragma unroll
@@ -191,7 +241,7 @@ attn_kernel(const AttnP p) {
 template <typename T, int DT>
 static int attn_launch_dt(const AttnP& p, hipStream_t st) {
     constexpr int ESZ = AMma<T>::ESZ;
-    constexpr size_t lds = (size_t)KT * (DT * 32 * ESZ + 16) + (size_t)DT * 32 * (KT * ESZ + 16);
+    constexpr size_t lds = (size_t)KT * (DT * 32 * ESZ + 16) + (size_t)DT * 32 * (KT * ESZ + (ESZ == 2 ? 8 : 16));
     static bool attr_set = false;                 // opt in once per instantiation (> 64 KiB for f32, d = 128)
     if (!attr_set) {
         ADVS_HIP(hipFuncSetAttribute((const void*)attn_kernel<T, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
