@@ -209,7 +209,7 @@ gn_stats_fold_kernel(const float* __restrict__ st1, int rbpi1, int C1, const flo
         if (Cs == 0) continue;
         const int per = (rbpi + nsplit - 1) / nsplit;
         const int r0 = chunk * per, r1 = min(rbpi, r0 + per);
-        const int rows_par = Cs < 256 ? 256 / Cs : 1;
+        const int rows_par = Cs < 256 ? (256 / Cs < 4 ? 256 / Cs : 4) : 1;      // tmp holds 4 row lanes
         const int rl = Cs < 256 ? tid / Cs : 0, cl = Cs < 256 ? tid - rl * Cs : tid;
         for (int c0 = 0; c0 < Cs; c0 += 256) {
             const int c = c0 + cl;
@@ -219,7 +219,7 @@ gn_stats_fold_kernel(const float* __restrict__ st1, int rbpi1, int C1, const flo
                     const float2 e = *(const float2*)(st + (((size_t)b * rbpi + r) * Cs + c) * 2);
                     s += (double)e.x; q += (double)e.y;
                 }
-            tmp[(rl * 256 + cl) * 2] = s; tmp[(rl * 256 + cl) * 2 + 1] = q;
+            if (rl < rows_par) { tmp[(rl * 256 + cl) * 2] = s; tmp[(rl * 256 + cl) * 2 + 1] = q; }
             __syncthreads();
             if (rl == 0 && c < Cs) {
                 for (int l = 1; l < rows_par; ++l) { s += tmp[(l * 256 + cl) * 2]; q += tmp[(l * 256 + cl) * 2 + 1]; }

@@ -522,6 +522,22 @@ def test_groupnorm_residual_after_activation(dt):
     assert err < tol(dt, 2e-5, 6e-2), err
 
 
+@pytest.mark.parametrize("dt", DTS)
+def test_groupnorm_with_epilogue_stats_narrow_channels(dt):
+    """32- and 64-channel producers (CSPDarkUnet's stem level): the fold kernel packs several row lanes per pass."""
+    for C, groups in ((32, 1), (64, 32), (96, 1)):
+        B, H, W = 2, 16, 16
+        x, w = rnd(B, 64, H, W, seed=91), rnd(C, 64, 1, 1, seed=92, scale=0.2)
+        g, be = rnd(C, seed=93) + 1, rnd(C, seed=94)
+        op = OneOp(dt, B)
+        y = op.b.conv(nhwc(x, dt), pack_conv_weight(w.to(dev()), dtype_code(dt)), C, ksize=1, pad=0, want_stats=True)
+        assert y.data_ptr() in op.b.stats
+        n = op.b.groupnorm(y, g.to(dev()), be.to(dev()), groups, act="silu")
+        op.go()
+        ref = F.silu(F.group_norm(nchw(y), groups, g, be, eps=1e-5))
+        assert (nchw(n) - ref).abs().max().item() < tol(dt, 2e-5, 4e-2), (C, groups)
+
+
 def test_unknown_dtype_code_is_rejected():
     """Every entry point that takes a dtype code refuses one it does not know (no silent f32 interpretation)."""
     lib = _lib.load()
