@@ -27,7 +27,7 @@ template <> struct AMma<F16> { static constexpr int ESZ = 2; };
 template <> struct AMma<float> { static constexpr int ESZ = 4; };
 
 template <typename T, int DT>
-__global__ void __launch_bounds__(AT_THREADS)
+__global__ void __launch_bounds__(AT_THREADS, 2)
 attn_kernel(const AttnP p) {
     constexpr int ESZ = AMma<T>::ESZ;
     constexpr int VEC = 16 / ESZ;
@@ -81,52 +81,64 @@ attn_kernel(const AttnP p) {
     constexpr int NQ = (DMAX * ESZ + 255) / 256;  // V key-quads per thread per tile: 16 quads x (d*ESZ/16) chunks / 256
     u32x4 kreg[NV], vreg[NQ][4];
     const int nquad = (KT / 4) * cpr;
+    // tile-invariant staging geometry of this thread (the divisions by the runtime chunk counts happen once, not per tile)
+    int k_key[NV], k_goff[NV], k_loff[NV], v_key0[NQ], v_goff[NQ], v_loff[NQ];   // key < 0: nothing to do
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = tid + i * AT_THREADS, key = v / cprp, ch = v - key * cprp;
+        k_key[i] = v < nvec ? (ch < cpr ? key : key | 0x40000000) : -1;             // bit 30: the zero half-step chunk
+        k_goff[i] = ch * 16;
+        k_loff[i] = key * KS + ch * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const int v = tid + i * AT_THREADS, kq = v / cpr, ch = v - kq * cpr;
+        v_key0[i] = v < nquad ? 4 * kq : -1;
+        v_goff[i] = ch * 16;
+        v_loff[i] = (ESZ == 2) ? (ch * 8) * VS + kq * 8 : (ch * 4) * VS + kq * 16;
+    }
     auto fetch = [&](int k0) {
+        const bool edge = k0 + KT > p.N;              // only the last tile of a short sequence needs the row checks
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int v = tid + i * AT_THREADS;
             kreg[i] = u32x4{0, 0, 0, 0};
-            if (v < nvec) {
-                const int key = v / cprp, ch = v - key * cprp;
-                if (ch < cpr && k0 + key < p.N) kreg[i] = *(const u32x4*)(kp + (size_t)(k0 + key) * rowb + ch * 16);
-            }
+            const int key = k_key[i];
+            if (key >= 0 && !(key & 0x40000000) && (!edge || k0 + key < p.N))
+                kreg[i] = *(const u32x4*)(kp + (size_t)(k0 + key) * rowb + k_goff[i]);
         }
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
-            const int v = tid + i * AT_THREADS;
-            const int kq = v / cpr, ch = v - kq * cpr;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int key = k0 + 4 * kq + j;      // the last tile of a short sequence (N = 16 at 4x4) is zero-filled
-                vreg[i][j] = (v < nquad && key < p.N) ? *(const u32x4*)(vp + (size_t)key * rowb + ch * 16) : u32x4{0, 0, 0, 0};
+                const int key = v_key0[i] + j;
+                vreg[i][j] = (v_key0[i] >= 0 && (!edge || k0 + key < p.N)) ? *(const u32x4*)(vp + (size_t)(k0 + key) * rowb + v_goff[i])
+                                                                            : u32x4{0, 0, 0, 0};
             }
         }
     };
     auto commit = [&]() {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int v = tid + i * AT_THREADS;
-            if (v >= nvec) continue;
-            const int key = v / cprp, ch = v - key * cprp;
-            *(u32x4*)(sK + key * KS + ch * 16) = kreg[i];          // chunks >= cpr: the zero half step
-        }
+        for (int i = 0; i < NV; ++i)
+            if (k_key[i] >= 0) *(u32x4*)(sK + k_loff[i]) = kreg[i];          // incl. the zero half-step chunk
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
-            const int v = tid + i * AT_THREADS;
-            if (v >= nquad) continue;
-            const int kq = v / cpr, ch = v - kq * cpr;
+            if (v_key0[i] < 0) continue;
+            char* dst = sV + v_loff[i];
             if (ESZ == 2) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {                      // row d = 8 ch + e gets keys 4kq .. 4kq+3 (8 bytes)
-                    const int w = e >> 1, sh = (e & 1) * 16;
-                    const unsigned k01 = ((vreg[i][0][w] >> sh) & 0xffffu) | (((vreg[i][1][w] >> sh) & 0xffffu) << 16);
-                    const unsigned k23 = ((vreg[i][2][w] >> sh) & 0xffffu) | (((vreg[i][3][w] >> sh) & 0xffffu) << 16);
-                    *(u32x2*)(sV + (ch * 8 + e) * VS + kq * 8) = u32x2{k01, k23};
+                for (int w = 0; w < 4; ++w) {          // rows d = 8 ch + 2w, 2w + 1 get keys 4kq .. 4kq+3 (8 bytes each)
+                    // v_perm_b32 picks the low / high halves of two dwords: {hi(a), hi(b)} <- 0x07060302, lo <- 0x05040100
+                    const unsigned lo01 = __builtin_amdgcn_perm(vreg[i][1][w], vreg[i][0][w], 0x05040100u);
+                    const unsigned lo23 = __builtin_amdgcn_perm(vreg[i][3][w], vreg[i][2][w], 0x05040100u);
+                    const unsigned hi01 = __builtin_amdgcn_perm(vreg[i][1][w], vreg[i][0][w], 0x07060302u);
+                    const unsigned hi23 = __builtin_amdgcn_perm(vreg[i][3][w], vreg[i][2][w], 0x07060302u);
+                    *(u32x2*)(dst + (2 * w) * VS) = u32x2{lo01, lo23};
+                    *(u32x2*)(dst + (2 * w + 1) * VS) = u32x2{hi01, hi23};
                 }
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    *(u32x4*)(sV + (ch * 4 + e) * VS + kq * 16) = u32x4{vreg[i][0][e], vreg[i][1][e], vreg[i][2][e], vreg[i][3][e]};
+                    *(u32x4*)(dst + e * VS) = u32x4{vreg[i][0][e], vreg[i][1][e], vreg[i][2][e], vreg[i][3][e]};
             }
         }
     };
@@ -142,11 +154,10 @@ attn_kernel(const AttnP p) {
         f32x16 st[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
+            st[kb] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < QSTEPS; ++s) {
-                if (s < dsteps) {
+                if (s == 0 || s < dsteps) {                 // step 0 always exists: its C operand folds to the constant 0
                     const u32x4 kf = *(const u32x4*)(sK + (kb * 32 + l31) * KS + s * 32 + lh * 16);
                     if (ESZ == 2) {
                         if constexpr (ESZ == 2) st[kb] = mma16<T>(kf, qf[s], st[kb]);
