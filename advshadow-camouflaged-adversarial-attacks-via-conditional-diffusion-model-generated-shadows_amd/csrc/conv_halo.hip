@@ -41,10 +41,22 @@ __device__ __forceinline__ void halo_row_map(int r, int& g, int& idx) {
     idx = before * 4 + (r & 3);
 }
 
-template <typename T>
+// NT = 9: the 3x3 convolution.  NT = 4: the SUB-PIXEL form of "nearest x2 upsample, then 3x3" (Upsample,
+// diff_model.py:129-140).  Output pixel (2i+a, 2j+b) only ever sees input rows {i-1, i} (a = 0) or {i, i+1} (a = 1),
+// and likewise for columns, so each of the four output parities is a 2x2 convolution of the LOW-resolution input
+// with weights summed over the taps that coincide (packed per parity by the host: [parity][Cout][2x2][Cin]).
+// 4 taps per slab instead of 9: 2.25x fewer MACs than convolving the upsampled image, no upsampled tensor.
+// A workgroup then owns (16x16 low-res pixels, one parity, 128 channels) = 256 of the 1024 output pixels above it.
+template <int NT> __host__ __device__ constexpr int halo_a_pieces(int t) {
+    // halo pieces of the next slab issued during tap t; none in the last two taps (see the wait at the tap top)
+    return NT == 9 ? ((t >= 0 && t < HNP) ? 1 : 0) : ((t == 0 || t == 1) ? 3 : 0);
+}
+
+template <typename T, int NT>
 __global__ void __launch_bounds__(512)
 conv3x3_halo_kernel(const ConvKP p) {
     constexpr int ESZ = Mma<T>::ESZ;
+    constexpr int NTW = NT == 9 ? 3 : 2;                         // taps per filter row
     constexpr int BKE = SLAB / ESZ;
     extern __shared__ __attribute__((aligned(1024))) char smem[];   // [2][HA_STAGE] then [4][HB_STAGE]
     char* sA = smem;
@@ -57,13 +69,16 @@ conv3x3_halo_kernel(const ConvKP p) {
     // ---- workgroup -> (image, pixel tile, channel tile); channel tiles of one pixel tile are neighbours
     // on one XCD so the halo is re-read from that XCD's L2
     const int tiles_x = p.W / HT, tpi = tiles_x * (p.H / HT);
-    const int nblk = p.nMt * p.nNt;
+    constexpr int NPAR = NT == 9 ? 1 : 4;                        // output parities per pixel tile
+    const int nblk = p.nMt * NPAR * p.nNt;
     int bid = blockIdx.x;
     {
         const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int tl = bid / p.nNt, nt = bid - tl * p.nNt;
+    const int tl = bid / (NPAR * p.nNt), brem = bid - tl * (NPAR * p.nNt);
+    const int par = brem / p.nNt, nt = brem - par * p.nNt;       // parity (a, b) = (par >> 1, par & 1)
+    const int r0 = NT == 9 ? 0 : par >> 1, s0 = NT == 9 ? 0 : par & 1;
     const int b = tl / tpi, ti = tl - b * tpi;
     const int ty = ti / tiles_x, tx = ti - ty * tiles_x;
     const int y0 = ty * HT, x0 = tx * HT, n0 = nt * 128;
@@ -87,7 +102,7 @@ conv3x3_halo_kernel(const ConvKP p) {
     for (int j = 0; j < 2; ++j) {
         const int row = (wave * 2 + j) * 8 + (lane >> 3);
         const int n = n0 + row;
-        b_voff[j] = (n < p.Cout) ? (unsigned)n * (unsigned)p.K * ESZ + ((chunk ^ ((row >> 1) & 7)) << 4) : OOB_OFFSET;
+        b_voff[j] = (n < p.Cout) ? (unsigned)(par * p.Cout + n) * (unsigned)p.K * ESZ + ((chunk ^ ((row >> 1) & 7)) << 4) : OOB_OFFSET;
     }
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x1, 0, p.x1_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x2 ? p.x2 : p.x1), 0, p.x2_bytes, 0x00020000);
@@ -95,7 +110,6 @@ conv3x3_halo_kernel(const ConvKP p) {
 
     const int Cin = p.C1 + p.C2;
     const int ncs1 = p.C1 / BKE, nunits = Cin / BKE;   // one unit = one 128-byte channel slab (all 9 taps)
-    const int total_it = nunits * 9;
 
     auto set_a_voff = [&](int unit) {                // byte offsets of the halo pixels in `unit`'s source
         const unsigned cs = (unsigned)(unit < ncs1 ? p.LD1 : p.LD2) * ESZ;
@@ -109,7 +123,7 @@ conv3x3_halo_kernel(const ConvKP p) {
     };
     auto issue_B = [&](int unit, int t, int j) {     // weights of (slab unit, tap t): K offset t*Cin + unit*BKE
         const unsigned woff = (unsigned)(t * Cin + unit * BKE) * ESZ;
-        blds16(rsw, b_voff[j], woff, sB + ((unit * 9 + t) & 3) * HB_STAGE + (wave * 2 + j) * 1024);
+        blds16(rsw, b_voff[j], woff, sB + ((unit * NT + t) & 3) * HB_STAGE + (wave * 2 + j) * 1024);
     };
 
     // ---- fragment geometry: wave (wr, wc) owns tile rows 4wr..4wr+3 (x16 px) and channels wc*64..+63
@@ -156,18 +170,19 @@ conv3x3_halo_kernel(const ConvKP p) {
         const char* la = sA + (unit & 1) * HA_STAGE;
         auto tap = [&](auto tc) {
             constexpr int t = decltype(tc)::value;
-            const int it = unit * 9 + t;
-            // Outstanding, oldest first: W(t+1) [+halo piece t-2], W(t+2) [+halo piece t-1].  Wait for W(t+1).
-            constexpr int nA = ((t - 2 >= 0 && t - 2 < HNP) ? 1 : 0) + ((t - 1 >= 0 && t - 1 < HNP) ? 1 : 0);
+            const int it = unit * NT + t;
+            // Outstanding, oldest first: W(t+1) [+halo pieces of tap t-2], W(t+2) [+halo pieces of tap t-1].  Wait for
+            // W(t+1).  The last tap of a slab reads the NEXT slab's halo at its end: everything but W(t+2) must be in.
+            constexpr int nA = t == NT - 1 ? 0 : halo_a_pieces<NT>(t - 2) + halo_a_pieces<NT>(t - 1);
             if (hn) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + nA) : "memory");
-            else if (t < 7) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if (t + 2 < NT) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            // W(it+3) wraps into the next slab for t = 6, 7, 8
-            const bool wb = t < 6 || hn;
-            const int u3 = t < 6 ? unit : unit + 1, t3 = t < 6 ? t + 3 : t - 6;
-            const int r = t / 3, s = t % 3;
+            // W(it+3) wraps into the next slab for the last three taps
+            const bool wb = t + 3 < NT || hn;
+            const int u3 = t + 3 < NT ? unit : unit + 1, t3 = t + 3 < NT ? t + 3 : t + 3 - NT;
+            const int r = r0 + t / NTW, s = s0 + t % NTW;
             const char* lb = sB + (it & 3) * HB_STAGE;
             if (it == 0) load_frags(0, la, lb, r, s, 0);              // nothing was carried into the very first tap
 #pragma unroll
@@ -175,15 +190,19 @@ conv3x3_halo_kernel(const ConvKP p) {
                 const int cur = ks & 1, nxt = cur ^ 1;
                 if (ks < 3) {
                     load_frags(nxt, la, lb, r, s, ks + 1);
-                } else if (t < 8) {                                   // first fragments of the next tap, same slab
-                    load_frags(nxt, la, sB + ((it + 1) & 3) * HB_STAGE, (t + 1) / 3, (t + 1) % 3, 0);
+                } else if (t < NT - 1) {                              // first fragments of the next tap, same slab
+                    load_frags(nxt, la, sB + ((it + 1) & 3) * HB_STAGE, r0 + (t + 1) / NTW, s0 + (t + 1) % NTW, 0);
                 } else if (hn) {                                      // ... or tap 0 of the next slab's halo
-                    load_frags(nxt, sA + ((unit + 1) & 1) * HA_STAGE, sB + ((it + 1) & 3) * HB_STAGE, 0, 0, 0);
+                    load_frags(nxt, sA + ((unit + 1) & 1) * HA_STAGE, sB + ((it + 1) & 3) * HB_STAGE, r0, s0, 0);
                 }
                 // this tap's share of the DMA issue, spread between the MFMA groups (weights first)
                 if (ks == 0 && wb) issue_B(u3, t3, 0);
                 if (ks == 1 && wb) issue_B(u3, t3, 1);
-                if (ks == 2 && hn && t < HNP) issue_A(unit + 1, t);
+                if (NT == 9) {
+                    if (ks == 2 && hn && t < HNP) issue_A(unit + 1, t);
+                } else if (hn && t < 2) {                             // three halo pieces in each of taps 0 and 1
+                    if (ks >= 1) issue_A(unit + 1, 3 * t + ks - 1);
+                }
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
@@ -193,8 +212,11 @@ conv3x3_halo_kernel(const ConvKP p) {
             }
         };
         tap(std::integral_constant<int, 0>{}); tap(std::integral_constant<int, 1>{}); tap(std::integral_constant<int, 2>{});
-        tap(std::integral_constant<int, 3>{}); tap(std::integral_constant<int, 4>{}); tap(std::integral_constant<int, 5>{});
-        tap(std::integral_constant<int, 6>{}); tap(std::integral_constant<int, 7>{}); tap(std::integral_constant<int, 8>{});
+        tap(std::integral_constant<int, 3>{});
+        if constexpr (NT == 9) {
+            tap(std::integral_constant<int, 4>{}); tap(std::integral_constant<int, 5>{}); tap(std::integral_constant<int, 6>{});
+            tap(std::integral_constant<int, 7>{}); tap(std::integral_constant<int, 8>{});
+        }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                    // every wave is done reading before the patches reuse LDS
@@ -203,9 +225,11 @@ conv3x3_halo_kernel(const ConvKP p) {
                                [&](int lr) {
                                    int g, idx;
                                    halo_row_map(lr & 31, g, idx);
-                                   return (b * p.H + y0 + 4 * wr + 2 * (lr >> 5) + g) * p.W + x0 + idx;
+                                   const int yy = y0 + 4 * wr + 2 * (lr >> 5) + g, xx = x0 + idx;      // input-grid pixel
+                                   if (NT == 9) return (b * p.H + yy) * p.W + xx;
+                                   return (b * 2 * p.H + 2 * yy + r0) * (2 * p.W) + 2 * xx + s0;       // its parity's output
                                },
-                               p.temb ? b : -1, tl * 4 + wr);
+                               p.temb ? b : -1, (tl * NPAR + par) * 4 + wr);
 }
 
 // Can this launch use the halo kernel?  3x3, stride 1, pad 1, no upsample, no extra operand, image a
@@ -214,20 +238,46 @@ bool conv_halo_eligible(const ConvKP& p) {
     return p.R == 3 && p.stride == 1 && p.pad == 1 && p.ups == 0 && p.e1 == nullptr &&
            p.H % HT == 0 && p.W % HT == 0 && p.Ho == p.H && p.Wo == p.W;
 }
+// ... and the sub-pixel form of upsample + 3x3 (weights packed per output parity)?
+bool conv_halo_subpixel_eligible(const ConvKP& p) {
+    return p.R == 3 && p.stride == 1 && p.pad == 1 && p.ups == 1 && p.e1 == nullptr &&
+           p.H % HT == 0 && p.W % HT == 0 && p.Ho == 2 * p.H && p.Wo == 2 * p.W;
+}
 
 template <typename T>
 static int halo_launch(ConvKP& p, hipStream_t st) {
     constexpr int lds = 2 * HA_STAGE + 4 * HB_STAGE;
     static bool attr_set = false;
     if (!attr_set) {
-        ADVS_HIP(hipFuncSetAttribute((const void*)conv3x3_halo_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        ADVS_HIP(hipFuncSetAttribute((const void*)conv3x3_halo_kernel<T, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
     p.nMt = p.B * (p.H / HT) * (p.W / HT);
     p.nNt = cdiv(p.Cout, 128);
-    conv3x3_halo_kernel<T><<<p.nMt * p.nNt, 512, lds, st>>>(p);
+    conv3x3_halo_kernel<T, 9><<<p.nMt * p.nNt, 512, lds, st>>>(p);
     ADVS_CHECK_LAUNCH("conv3x3_halo");
     return ADVS_OK;
+}
+
+template <typename T>
+static int halo_subpixel_launch(ConvKP& p, hipStream_t st) {
+    constexpr int lds = 2 * HA_STAGE + 4 * HB_STAGE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        ADVS_HIP(hipFuncSetAttribute((const void*)conv3x3_halo_kernel<T, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    p.nMt = p.B * (p.H / HT) * (p.W / HT);
+    p.nNt = cdiv(p.Cout, 128);
+    conv3x3_halo_kernel<T, 4><<<p.nMt * 4 * p.nNt, 512, lds, st>>>(p);
+    ADVS_CHECK_LAUNCH("conv3x3_halo_subpixel");
+    return ADVS_OK;
+}
+
+int conv_halo_subpixel_dispatch(ConvKP& p, int dtype, hipStream_t st) {
+    ADVS_REQUIRE(conv_halo_subpixel_eligible(p), "conv2d: the sub-pixel upsample conv needs 3x3 stride 1 pad 1, upsample, no extra operand, H and W multiples of 16");
+    ADVS_SWITCH_T(dtype, return halo_subpixel_launch<T>(p, st));
+    return ADVS_ERR_ARG;                    // not reached
 }
 
 int conv_halo_dispatch(ConvKP& p, int dtype, hipStream_t st) {

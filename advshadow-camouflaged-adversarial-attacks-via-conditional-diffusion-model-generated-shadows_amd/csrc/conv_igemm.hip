@@ -312,6 +312,7 @@ static int conv_launch(ConvKP& p, hipStream_t st) {
 static int pick_tile(long long M, int cout);
 bool conv_halo_eligible(const ConvKP& p);
 int conv_halo_dispatch(ConvKP& p, int dtype, hipStream_t st);
+int conv_halo_subpixel_dispatch(ConvKP& p, int dtype, hipStream_t st);
 
 template <typename T>
 static int conv_dispatch(ConvKP& p, int tile, hipStream_t st) {
@@ -346,6 +347,7 @@ static int pick_tile(long long M, int cout) {
 // the 16x16-pixel halo kernel wins wherever it applies (3x3, stride 1, no upsample / extra operand, image a
 // multiple of 16: +15..30 % over the per-tap tiles on every such layer of the eps-predictor, tools/tune_conv.py)
 static int resolve_tile(const advs_conv_args* a, long long M) {
+    if (a->upsample == ADVS_UPSAMPLE_SUBPIXEL) return 12;       // weights are packed per output parity: one kernel only
     if (g_tile_override) return g_tile_override;
     if (a->tile) return a->tile;
     if (a->ksize == 3 && a->stride == 1 && a->pad == 1 && !a->upsample && !a->e1 && a->h % 16 == 0 && a->w_ % 16 == 0)
@@ -361,7 +363,7 @@ extern "C" int advs_conv_resolve_tile(const advs_conv_args* a) {
     return resolve_tile(a, (long long)a->b * ho * wo);
 }
 extern "C" int advs_conv_tile_rows(int tile) {
-    switch (tile) { case 1: case 2: case 5: case 6: case 8: case 10: return 64; case 3: case 4: case 7: case 9: return 128; default: return 0; }
+    switch (tile) { case 1: case 2: case 5: case 6: case 8: case 10: case 12: return 64; case 3: case 4: case 7: case 9: return 128; default: return 0; }
 }
 
 extern "C" int advs_conv2d(const advs_conv_args* a, void* stream) {
@@ -396,13 +398,19 @@ extern "C" int advs_conv2d(const advs_conv_args* a, void* stream) {
     ADVS_REQUIRE(M > 0 && M < (1ll << 31) - 256, "conv2d: M=%lld out of range", M);
     p.M = (int)M;
     p.K = a->ksize * a->ksize * (a->c1 + a->c2) + a->ce1 + a->ce2;
+    const bool subpixel = a->upsample == ADVS_UPSAMPLE_SUBPIXEL;
+    if (subpixel) {
+        ADVS_REQUIRE(a->ksize == 3 && a->stride == 1 && a->pad == 1 && !a->e1 && a->h % 16 == 0 && a->w_ % 16 == 0,
+                     "conv2d: ADVS_UPSAMPLE_SUBPIXEL needs 3x3 stride 1 pad 1, no extra operand, h and w multiples of 16");
+        p.K = 4 * (a->c1 + a->c2);                          // per parity: 2x2 taps; w holds [4][cout][4][c1 + c2]
+    }
     p.e1 = (const char*)a->e1; p.e2 = (const char*)a->e2; p.E1 = a->ce1; p.E2 = a->ce2;
     const unsigned long long e1b = (unsigned long long)M * a->ce1 * esz, e2b = (unsigned long long)M * a->ce2 * esz;
     ADVS_REQUIRE(e1b < 0xF0000000ull && e2b < 0xF0000000ull, "conv2d: extra operand exceeds the 32-bit buffer offsets");
     p.e1_bytes = (unsigned)(a->e1 ? e1b : 16); p.e2_bytes = (unsigned)(a->e2 ? e2b : 16);
     const unsigned long long x1b = (unsigned long long)a->b * a->h * a->w_ * p.LD1 * esz;
     const unsigned long long x2b = (unsigned long long)a->b * a->h * a->w_ * p.LD2 * esz;
-    const unsigned long long wb = (unsigned long long)a->cout * p.K * esz;
+    const unsigned long long wb = (unsigned long long)a->cout * p.K * esz * (subpixel ? 4 : 1);
     ADVS_REQUIRE(x1b < 0xF0000000ull && x2b < 0xF0000000ull && wb < 0xF0000000ull,
                  "conv2d: a source of %llu bytes exceeds the 32-bit buffer offsets (split the batch)", x1b > x2b ? x1b : x2b);
     p.x1_bytes = (unsigned)x1b; p.x2_bytes = (unsigned)(a->x2 ? x2b : x1b); p.w_bytes = (unsigned)wb;
@@ -420,6 +428,7 @@ extern "C" int advs_conv2d(const advs_conv_args* a, void* stream) {
         if (g_tile_override && a->stats_rows != wm) p.stats = nullptr;   // tuning runs: buffer sized for another tile
         else ADVS_REQUIRE(a->stats_rows == wm, "conv2d: stats buffer sized for %d-row blocks but the tile uses %d", a->stats_rows, wm);
     }
+    if (tile == 12) return conv_halo_subpixel_dispatch(p, a->dtype, (hipStream_t)stream);
     if (tile == 10) return conv_halo_dispatch(p, a->dtype, (hipStream_t)stream);
     ADVS_SWITCH_T(a->dtype, return conv_dispatch<T>(p, tile, (hipStream_t)stream));
     return ADVS_ERR_ARG;                    // not reached

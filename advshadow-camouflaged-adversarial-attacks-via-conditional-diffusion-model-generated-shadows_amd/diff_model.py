@@ -18,7 +18,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
-from .engine import BF16, F32, Builder, dtype_code, pack_conv_weight, ptr, SLAB_ELEMS
+from .engine import (BF16, F32, Builder, dtype_code, pack_conv_weight, pack_subpixel_upsample_weight, ptr, SLAB_ELEMS,
+                     subpixel_upsample_eligible)
 from ._lib import check
 
 
@@ -195,6 +196,7 @@ class UNetModel(nn.Module):
                     W[p + ".op.b"] = sd[p + ".op.bias"].float().contiguous()
                 elif kind == "up":
                     W[p + ".conv.w"] = pack_conv_weight(sd[p + ".conv.weight"], dt)
+                    W[p + ".conv.w4"] = pack_subpixel_upsample_weight(sd[p + ".conv.weight"], dt)   # four-parity 2x2 form
                     W[p + ".conv.b"] = sd[p + ".conv.bias"].float().contiguous()
         W["temb_w"] = torch.cat(temb_w, 0).contiguous()       # every block's Linear(512 -> cout), stacked
         W["temb_b"] = torch.cat(temb_b, 0).contiguous()
@@ -321,7 +323,11 @@ def emit_unet_forward(bld, model, W, x_nchw, t_dev, eps_out):
             elif kind == "down":
                 new = bld.conv(h, W[p + ".op.w"], cout, bias=W[p + ".op.b"], stride=2, want_stats=True)
             elif kind == "up":
-                new = bld.conv(h, W[p + ".conv.w"], cout, bias=W[p + ".conv.b"], upsample=True, want_stats=True)
+                # Upsample (diff_model.py:129-140): nearest x2 + 3x3, computed on the low-res grid where the shape allows
+                if subpixel_upsample_eligible(h.shape[1], h.shape[2]):
+                    new = bld.conv(h, W[p + ".conv.w4"], cout, bias=W[p + ".conv.b"], upsample="subpixel", want_stats=True)
+                else:
+                    new = bld.conv(h, W[p + ".conv.w"], cout, bias=W[p + ".conv.b"], upsample=True, want_stats=True)
             if h is not None and not any(h is s for s in hs):
                 bld.free(h)
             h = new

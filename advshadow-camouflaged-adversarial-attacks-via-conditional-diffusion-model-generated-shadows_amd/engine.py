@@ -151,17 +151,18 @@ class Builder:
         # K extent C (rounded up); pack_conv_weight zero-fills the weights of the surplus channels
         slab = SLAB_ELEMS[self.dt]
         C1, C2 = -(-L1 // slab) * slab, -(-L2 // slab) * slab
+        subpixel = upsample == "subpixel"                 # weights from pack_subpixel_upsample_weight
         HL, WL = (H * 2, W * 2) if upsample else (H, W)
         Ho = (HL + 2 * pad - ksize) // stride + 1
         Wo = (WL + 2 * pad - ksize) // stride + 1
         y = out if out is not None else self.buf((B, Ho, Wo, cout))
         a = ConvArgs(ptr(x1), ptr(x2), ptr(w), ptr(bias), ptr(temb), ptr(residual), ptr(y),
-                     B, H, W, C1, C2, cout, ksize, stride, pad, 1 if upsample else 0,
+                     B, H, W, C1, C2, cout, ksize, stride, pad, 2 if subpixel else (1 if upsample else 0),
                      ACT[act], self.dt, temb_stride, tile, 0, 0,
                      ptr(extra[0]) if extra else 0, ptr(extra[1]) if extra and extra[1] is not None else 0,
                      extra[0].shape[3] if extra else 0, extra[1].shape[3] if extra and extra[1] is not None else 0,
                      L1 if L1 != C1 else 0, L2 if L2 != C2 else 0)
-        kw = ksize * ksize * (C1 + C2) + a.ce1 + a.ce2
+        kw = 16 * (C1 + C2) if subpixel else ksize * ksize * (C1 + C2) + a.ce1 + a.ce2
         if w.numel() != cout * kw:
             raise ValueError(f"conv: packed weight has {w.numel()} elements, expected {cout} x {kw} "
                              f"(sources {L1}+{L2} channels, slab {slab})")
@@ -264,6 +265,26 @@ class Builder:
         self.plan.add(self.lib.advs_timestep_embedding, ptr(t), ptr(freqs), half, 1 if cos_first else 0, ptr(table),
                       ptr(labels), ptr(y), self.B, keep=(t, freqs, table, labels, y))
         return y
+
+
+def subpixel_upsample_eligible(h, w, ksize=3):
+    """Can "nearest x2 then 3x3" on an h x w input run as the four-parity 2x2 form (advs_conv_args.upsample = 2)?"""
+    return ksize == 3 and h % 16 == 0 and w % 16 == 0
+
+
+def pack_subpixel_upsample_weight(w, dt):
+    """OIHW 3x3 weight of a conv that follows a nearest x2 upsample -> [4][O][2][2][I] in the compute dtype:
+    for output parity (a, b) the taps that read the same low-res pixel are summed (in f32, before rounding):
+    rows {w0, w1 + w2} for a = 0 and {w0 + w1, w2} for a = 1, columns likewise (include/advshadow.h)."""
+    w = w.detach().float()
+    rows = (torch.stack([w[:, :, 0], w[:, :, 1] + w[:, :, 2]], 2), torch.stack([w[:, :, 0] + w[:, :, 1], w[:, :, 2]], 2))
+    parts = []
+    for a in (0, 1):
+        r = rows[a]                                            # [O, I, 2, 3]
+        for b in (0, 1):
+            c = torch.stack([r[..., 0], r[..., 1] + r[..., 2]], 3) if b == 0 else torch.stack([r[..., 0] + r[..., 1], r[..., 2]], 3)
+            parts.append(pack_conv_weight(c, dt))              # [O][2][2][I]
+    return torch.stack(parts, 0).contiguous()
 
 
 def pack_conv_weight(w, dt, stream=None, sources=None):

@@ -55,6 +55,7 @@ int advs_nhwc_to_nchw_f32(const void* x, float* y, int b, int c, int h, int w, i
  *   - bias[n], temb[b][n] (h += time_emb(t)[:, :, None, None], diff_model.py:101),
  *     residual[m][n] (h + shortcut(x), diff_model.py:103,127), activation.
  * Requirements: c1 and c2 multiples of 64 (bf16) / 32 (f32).                               */
+#define ADVS_UPSAMPLE_SUBPIXEL 2
 typedef struct advs_conv_args {
     const void* x1; const void* x2;     /* NHWC sources [b][h][w][c1], [b][h][w][c2]        */
     const void* w;                      /* packed [cout][r][r][c1+c2]                       */
@@ -63,11 +64,17 @@ typedef struct advs_conv_args {
     const void* residual;               /* NHWC [b][ho][wo][cout] or NULL                   */
     void* y;                            /* NHWC [b][ho][wo][cout]                           */
     int b, h, w_, c1, c2, cout;         /* h,w_: stored source size (before upsample)       */
-    int ksize, stride, pad, upsample;   /* ksize 1|3; upsample 0|1                          */
+    int ksize, stride, pad, upsample;   /* ksize 1|3; upsample 0 | 1 (nearest x2 on load) | ADVS_UPSAMPLE_SUBPIXEL:
+                                           the same function computed as four 2x2 convolutions of the low-res input,
+                                           one per output parity (2.25x fewer MACs); w is then [4][cout][2][2][c1+c2],
+                                           parity (a,b) = 2a+b, with the coinciding taps of the 3x3 kernel summed:
+                                           rows {w0, w1+w2} for a = 0, {w0+w1, w2} for a = 1, columns likewise.
+                                           3x3 stride 1 pad 1, h and w multiples of 16.                          */
     int act, dtype;
     int temb_stride;                    /* floats between consecutive samples' temb rows    */
     int tile;                           /* 0 = choose; 1: 128x128, 2|3: 256x128, 4: 256x256,
-                                           10: 16x16-pixel halo tile (3x3 stride 1 only)       */
+                                           10: 16x16-pixel halo tile (3x3 stride 1 only); 12 (implied by
+                                           ADVS_UPSAMPLE_SUBPIXEL): its 4-tap sub-pixel form                  */
     float* stats;                       /* NULL, or [ceil(M/rows)][cout][2]: per row block (rows =
                                            advs_conv_tile_rows(tile), must divide ho*wo) and channel the
                                            (sum, sum of squares) of y as stored -> advs_groupnorm_stats */

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 from gpu_helpers import OneOp, bf16_round, dev, lp_round, nchw, nhwc, tdt  # noqa: E402
 from advshadow_amd import _lib  # noqa: E402
-from advshadow_amd.engine import pack_conv_weight, dtype_code, ptr  # noqa: E402
+from advshadow_amd.engine import pack_conv_weight, pack_subpixel_upsample_weight, dtype_code, ptr  # noqa: E402
 
 DTS = ["fp32", "bf16", "fp16"]
 
@@ -536,6 +536,53 @@ def test_groupnorm_with_epilogue_stats_narrow_channels(dt):
         op.go()
         ref = F.silu(F.group_norm(nchw(y), groups, g, be, eps=1e-5))
         assert (nchw(n) - ref).abs().max().item() < tol(dt, 2e-5, 4e-2), (C, groups)
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("case", [
+    # B, H, W, C1, C2, Cout, bias, temb, res, act, stats
+    (1, 16, 16, 64, 0, 128, 1, 0, 0, None, 0), (2, 32, 16, 128, 0, 256, 1, 1, 1, "silu", 1), (1, 16, 48, 64, 64, 64, 0, 0, 0, None, 1),
+    (3, 16, 16, 256, 0, 256, 1, 0, 0, None, 0),
+])
+def test_conv2d_upsample_subpixel(case, dt):
+    """nearest x2 + 3x3 (Upsample, diff_model.py:129-140) as four 2x2 convolutions of the low-res input."""
+    B, H, W, C1, C2, Cout, has_b, has_t, has_r, act, stats = case
+    x1 = rnd(B, C1, H, W, seed=101)
+    x2 = rnd(B, C2, H, W, seed=102) if C2 else None
+    w = rnd(Cout, C1 + C2, 3, 3, seed=103, scale=1.0 / math.sqrt((C1 + C2) * 9))
+    bias = rnd(Cout, seed=104) if has_b else None
+    temb = rnd(B, Cout, seed=105) if has_t else None
+    xin = x1 if x2 is None else torch.cat([x1, x2], 1)
+    xin = lp_round(dt, xin)
+    ref = F.conv2d(F.interpolate(xin, scale_factor=2, mode="nearest"), lp_round(dt, w), bias, padding=1)
+    res = rnd(*ref.shape, seed=106) if has_r else None
+    if has_t:
+        ref = ref + temb[:, :, None, None]
+    if has_r:
+        ref = ref + lp_round(dt, res)
+    if act == "silu":
+        ref = F.silu(ref)
+    op = OneOp(dt, B)
+    w4 = pack_subpixel_upsample_weight(w.to(dev()), dtype_code(dt))
+    assert w4.shape == (4, Cout, 2, 2, C1 + C2)
+    y = op.b.conv(nhwc(x1, dt), w4, Cout, x2=nhwc(x2, dt) if C2 else None, bias=bias.to(dev()) if has_b else None,
+                  temb=temb.to(dev()) if has_t else None, temb_stride=Cout if has_t else 0,
+                  residual=nhwc(res, dt) if has_r else None, upsample="subpixel", act=act, want_stats=bool(stats))
+    n = None
+    if stats:
+        assert y.data_ptr() in op.b.stats
+        g, be = rnd(Cout, seed=107) + 1, rnd(Cout, seed=108)
+        n = op.b.groupnorm(y, g.to(dev()), be.to(dev()), 32, act="silu")
+    op.go()
+    got = nchw(y)
+    assert got.shape == ref.shape
+    # 16-bit modes: the summed taps are rounded once, the reference rounds each tap: allow that on top of the usual bound
+    err = (got - ref).abs().max().item()
+    assert err < tol(dt, 3e-5, 6e-2), err
+    if stats:
+        refn = F.silu(F.group_norm(got, 32, g, be, eps=1e-5))
+        rel = ((nchw(n) - refn).abs() / refn.abs().clamp(min=1.0)).max().item()     # outputs reach |8|: relative to the value
+        assert rel < tol(dt, 2e-5, 1e-2), rel
 
 
 def test_unknown_dtype_code_is_rejected():
