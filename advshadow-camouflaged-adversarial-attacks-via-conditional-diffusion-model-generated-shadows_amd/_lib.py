@@ -47,6 +47,8 @@ SIGNATURES = {
     "advs_concat_nearest2x": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "advs_layernorm": [vp, vp, vp, vp, C.c_longlong, i32, f32, i32, vp],
     "advs_attention_masked": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "advs_attention_bias": [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "advs_window_shift": [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "advs_dwconv2d": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "advs_space_to_depth2": [vp, vp, i32, i32, i32, i32, i32, vp],
     "advs_patchify": [vp, vp, i32, i32, i32, i32, i32, i32, vp],

@@ -19,6 +19,8 @@ struct AttnP {
     int B, N, heads, d, ld, q_off, k_off, v_off, head_stride;
     int n_valid;                 // keys >= n_valid are padding: masked out of the softmax
     float scale_log2e;
+    const float* bias;           // optional additive score bias [bias_mod][heads][N][N] (already times log2 e), or null
+    int bias_mod;                // sequence b uses bias block b % bias_mod (Swin: one block per window position)
 };
 
 template <typename T> struct AMma;
@@ -180,12 +182,25 @@ attn_kernel(const AttnP p) {
                     if (key >= p.n_valid) st[kb][r] = -INFINITY;
                 }
         }
+        float sc = p.scale_log2e;
+        if (p.bias) {                                       // relative-position bias (+ shift mask): scale now, add, and
+            const int query = q0 + l31;                     // continue with a unit scale
+            const float* bp = p.bias + ((size_t)((b % p.bias_mod) * p.heads + hd) * p.N + (query < p.N ? query : 0)) * p.N;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    st[kb][r] = fmaf(st[kb][r], sc, key < p.N ? bp[key] : 0.f);
+                }
+            sc = 1.0f;
+        }
         float mx = -INFINITY;                               // max of the RAW scores; the scale (> 0) is applied once
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kb][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32)) * p.scale_log2e;
+        mx = fmaxf(mx, __shfl_xor(mx, 32)) * sc;
         const float m_new = fmaxf(m_run, mx);
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);       // exp2(-inf) = 0 on the first tile
         float ls = 0.f;
@@ -193,7 +208,7 @@ attn_kernel(const AttnP p) {
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {                  // one FMA + one v_exp_f32 per score
-                st[kb][r] = __builtin_amdgcn_exp2f(fmaf(st[kb][r], p.scale_log2e, -m_new));
+                st[kb][r] = __builtin_amdgcn_exp2f(fmaf(st[kb][r], sc, -m_new));
                 ls += st[kb][r];
             }
         l_run = l_run * alpha + ls;
@@ -275,7 +290,8 @@ static int attn_launch(const AttnP& p, hipStream_t st) {
 }
 
 static int attention_impl(const void* qkv, void* out, int b, int n, int n_valid, int heads, int d, int ld,
-                          int q_off, int k_off, int v_off, int head_stride, int dtype, void* stream) {
+                          int q_off, int k_off, int v_off, int head_stride, int dtype, void* stream,
+                          const float* bias = nullptr, int bias_mod = 1) {
     ADVS_REQUIRE(qkv && out && b > 0 && n > 0 && heads > 0 && d > 0, "attention: bad args");
     ADVS_REQUIRE(n_valid > 0 && n_valid <= n, "attention: n_valid=%d out of range", n_valid);
     const int vec = dtype == ADVS_F32 ? 4 : 8;
@@ -287,6 +303,7 @@ static int attention_impl(const void* qkv, void* out, int b, int n, int n_valid,
     p.B = b; p.N = n; p.heads = heads; p.d = d; p.ld = ld;
     p.q_off = q_off; p.k_off = k_off; p.v_off = v_off; p.head_stride = head_stride; p.n_valid = n_valid;
     p.scale_log2e = (float)(1.4426950408889634 / sqrt((double)d));
+    p.bias = bias; p.bias_mod = bias_mod > 0 ? bias_mod : 1;
     ADVS_SWITCH_T(dtype, return attn_launch<T>(p, (hipStream_t)stream));
     return ADVS_ERR_ARG;                    // not reached
 }
@@ -302,4 +319,15 @@ extern "C" int advs_attention_masked(const void* qkv, void* out, int b, int n, i
                                      int q_off, int k_off, int v_off, int head_stride, int dtype, void* stream) {
     ADVS_REQUIRE(dtype_ok(dtype), "advs_attention_masked: unknown dtype code %d", dtype);
     return attention_impl(qkv, out, b, n, n_valid, heads, d, ld, q_off, k_off, v_off, head_stride, dtype, stream);
+}
+
+// Same with an additive score bias: softmax(q k^T / sqrt(d) + bias) v, bias [bias_mod][heads][n][n] f32 GIVEN IN
+// UNITS OF log2(e) (bias * 1.442695...), sequence i using block i % bias_mod -- Swin's relative position bias plus
+// the shifted-window mask of window position i % nW (WindowAttention.forward, timm swin_transformer.py).
+extern "C" int advs_attention_bias(const void* qkv, void* out, const float* bias_log2e, int bias_mod, int b, int n,
+                                   int heads, int d, int ld, int q_off, int k_off, int v_off, int head_stride, int dtype,
+                                   void* stream) {
+    ADVS_REQUIRE(dtype_ok(dtype), "advs_attention_bias: unknown dtype code %d", dtype);
+    ADVS_REQUIRE(bias_log2e && bias_mod > 0, "attention_bias: bias is required");
+    return attention_impl(qkv, out, b, n, n, heads, d, ld, q_off, k_off, v_off, head_stride, dtype, stream, bias_log2e, bias_mod);
 }

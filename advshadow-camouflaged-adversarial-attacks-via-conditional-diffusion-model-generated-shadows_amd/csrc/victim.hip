@@ -297,3 +297,58 @@ extern "C" int advs_space_to_depth2(const void* x, void* y, int b, int h, int w,
     ADVS_CHECK_LAUNCH("space_to_depth2");
     return ADVS_OK;
 }
+
+
+// ================================================================ Swin pieces (timm swin_base_patch4_window7_224, ASR_fast.py:27-32)
+// Cyclic shift + window partition in one gather (SwinTransformerBlock): tokens of window (wy, wx) are the pixels
+// ((wy*win + ty + shift) % H, (wx*win + tx + shift) % W) -- torch.roll(x, -shift) followed by window_partition.
+// inverse != 0 runs it backwards (window_reverse + roll(+shift)) and adds the block's residual in the same pass:
+// y[b][pixel] = windows[...] + residual[b][pixel].  x / y are [b][h][w][c] on the image side and
+// [b * (h/win) * (w/win)][win*win][c] on the window side.  HBM-bound: read + write once.
+template <typename T>
+__global__ void window_shift_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
+                                    int B, int H, int W, int C, int win, int shift, int inverse) {
+    constexpr int VEC = Elt<T>::VEC;
+    const int vpp = C / VEC, nwx = W / win, nwy = H / win;
+    const size_t total = (size_t)B * H * W * vpp;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % vpp);
+        size_t r = i / vpp;                          // window-side token index
+        const int tx = (int)(r % win); r /= win;
+        const int ty = (int)(r % win); r /= win;
+        const int wx = (int)(r % nwx); r /= nwx;
+        const int wy = (int)(r % nwy);
+        const int b = (int)(r / nwy);
+        int py = wy * win + ty + shift, px = wx * win + tx + shift;
+        if (py >= H) py -= H;
+        if (px >= W) px -= W;
+        const size_t img = (((size_t)b * H + py) * W + px) * vpp + cv;
+        if (!inverse) {
+            ((u32x4*)y)[i] = ((const u32x4*)x)[img];
+        } else {
+            float f[VEC], g[VEC];
+            unpack16<T>(((const u32x4*)x)[i], f);
+            if (res) {
+                unpack16<T>(((const u32x4*)res)[img], g);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) f[e] += g[e];
+            }
+            ((u32x4*)y)[img] = pack16<T>(f);
+        }
+    }
+}
+
+extern "C" int advs_window_shift(const void* x, const void* residual, void* y, int b, int h, int w, int c, int window,
+                                 int shift, int inverse, int dtype, void* stream) {
+    ADVS_REQUIRE(dtype_ok(dtype), "advs_window_shift: unknown dtype code %d", dtype);
+    ADVS_REQUIRE(x && y && b > 0 && h > 0 && w > 0 && window > 0 && h % window == 0 && w % window == 0,
+                 "window_shift: %dx%d is not a whole number of %d-pixel windows", h, w, window);
+    ADVS_REQUIRE(shift >= 0 && shift < window && (inverse || !residual), "window_shift: bad shift / residual");
+    const int vec = dtype == ADVS_F32 ? 4 : 8;
+    ADVS_REQUIRE(c % vec == 0, "window_shift: c=%d must be a multiple of %d", c, vec);
+    const size_t total = (size_t)b * h * w * (c / vec);
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    ADVS_SWITCH_T(dtype, window_shift_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T*)x, (const T*)residual, (T*)y, b, h, w, c, window, shift, inverse));
+    ADVS_CHECK_LAUNCH("window_shift");
+    return ADVS_OK;
+}

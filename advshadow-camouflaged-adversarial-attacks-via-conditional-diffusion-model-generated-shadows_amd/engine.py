@@ -251,6 +251,28 @@ class Builder:
                       q_off, k_off, v_off, head_stride, self.dt, keep=(qkv, y))
         return y
 
+    def attention_bias(self, qkv, heads, d, q_off, k_off, v_off, head_stride, bias_log2e, bias_mod):
+        """qkv [Bseq, 1, N, LD]; bias_log2e f32 [bias_mod][heads][N][N] (already times log2 e)."""
+        Bs, H, W, LD = qkv.shape
+        y = self.buf((Bs, H, W, heads * d))
+        self.plan.add(self.lib.advs_attention_bias, ptr(qkv), ptr(y), ptr(bias_log2e), bias_mod, Bs, H * W, heads, d, LD,
+                      q_off, k_off, v_off, head_stride, self.dt, keep=(qkv, y, bias_log2e))
+        return y
+
+    def window_shift(self, x, window, shift, inverse=False, residual=None, image_hw=None):
+        """Swin window partition (+ cyclic shift) and its inverse (+ residual); see advs_window_shift."""
+        if not inverse:
+            B, H, W, Cc = x.shape
+            y = self.buf((B * (H // window) * (W // window), 1, window * window, Cc))
+        else:
+            H, W = image_hw
+            Cc = x.shape[-1]
+            B = x.shape[0] // ((H // window) * (W // window))
+            y = self.buf((B, H, W, Cc))
+        self.plan.add(self.lib.advs_window_shift, ptr(x), ptr(residual), ptr(y), B, H, W, Cc, window, shift, 1 if inverse else 0,
+                      self.dt, keep=(x, residual, y))
+        return y
+
     def linear(self, x, w, bias, act_in=None, act_out=None):
         Bn, K = x.shape
         N = w.shape[0]

@@ -619,3 +619,261 @@ class _ConvNeXtEngine:
             self.plan.capture()
             self.captured = True
         self.plan.run()
+
+
+# ============================================================================ Swin (timm names)
+_SWIN_BASE = dict(embed_dim=128, depths=(2, 2, 18, 2), num_heads=(4, 8, 16, 32), window_size=7)
+
+
+def swin_canonical_state_dict(sd, depths):
+    """timm >= 0.9 names are canonical (``patch_embed.{proj,norm}``, ``layers.i.downsample.{norm,reduction}`` in front of
+    stage i >= 1, ``layers.i.blocks.j.{norm1,attn.{qkv,proj,relative_position_bias_table},norm2,mlp.fc1,mlp.fc2}``,
+    ``norm``, ``head.fc``).  Accepted as well: HF SwinForImageClassification names (separate q/k/v projections,
+    downsampling at the END of a stage) and the older timm layout (``layers.i.downsample`` after stage i, ``head.*``)."""
+    sd = dict(sd)
+    out = {}
+    if any(k.startswith("swin.") for k in sd):
+        for k, v in sd.items():
+            n = k.replace("swin.embeddings.patch_embeddings.projection.", "patch_embed.proj.").replace("swin.embeddings.norm.", "patch_embed.norm.")
+            n = n.replace("swin.layernorm.", "norm.").replace("classifier.", "head.fc.").replace("swin.encoder.layers.", "layers.")
+            n = n.replace(".layernorm_before.", ".norm1.").replace(".layernorm_after.", ".norm2.")
+            n = n.replace(".attention.relative_position_bias.relative_position_bias_table", ".attn.relative_position_bias_table")
+            n = n.replace(".attention.o_proj.", ".attn.proj.")
+            out[n] = v
+        for i, nb in enumerate(depths):
+            for j in range(nb):
+                p = f"layers.{i}.blocks.{j}"
+                for t in ("weight", "bias"):
+                    out[f"{p}.attn.qkv.{t}"] = torch.cat([out.pop(f"{p}.attention.{q}_proj.{t}") for q in "qkv"], 0)
+        sd, out = out, {}
+        old_layout = True                                   # HF merges at the end of stage i, like old timm
+    else:
+        old_layout = "layers.0.downsample.reduction.weight" in sd
+    for k, v in sd.items():
+        n = k
+        if old_layout and ".downsample." in k:
+            i = int(k.split(".")[1])
+            n = k.replace(f"layers.{i}.downsample.", f"layers.{i + 1}.downsample.")
+        if n in ("head.weight", "head.bias"):
+            n = n.replace("head.", "head.fc.")
+        if n.endswith("relative_position_index") or n.endswith("attn_mask"):
+            continue                                        # buffers that are functions of the window size
+        out[n] = v
+    return out
+
+
+class SwinVictim(nn.Module):
+    """``timm.create_model('swin_base_patch4_window7_224', num_classes=37)`` (ASR_fast.py:27-32) on the HIP kernels.
+    Per block: LayerNorm -> cyclic shift + window partition (one gather) -> qkv GEMM -> window attention with the
+    relative position bias and the shifted-window mask as an additive score bias -> projection GEMM -> inverse gather
+    (+ residual) -> LayerNorm -> MLP (GELU in the GEMM epilogue, residual in the second GEMM's).  Patch merging is a
+    space-to-depth gather + LayerNorm + GEMM (the 4C channel blocks are reordered on the host to the gather's order)."""
+
+    def __init__(self, num_classes=37, embed_dim=_SWIN_BASE["embed_dim"], depths=_SWIN_BASE["depths"],
+                 num_heads=_SWIN_BASE["num_heads"], window_size=_SWIN_BASE["window_size"], image_size=224, patch_size=4,
+                 mlp_ratio=4.0, compute_dtype="fp32", use_graph=True):
+        super().__init__()
+        self.num_classes, self.embed_dim, self.depths, self.num_heads = num_classes, embed_dim, tuple(depths), tuple(num_heads)
+        self.window_size, self.image_size, self.patch_size, self.mlp_ratio = window_size, image_size, patch_size, mlp_ratio
+        self.compute_dtype, self.use_graph = compute_dtype, use_graph
+        _attach(self, "patch_embed.proj", nn.Conv2d(3, embed_dim, patch_size, stride=patch_size))
+        _attach(self, "patch_embed.norm", nn.LayerNorm(embed_dim))
+        self._tables = []
+        for i, nb in enumerate(self.depths):
+            c = embed_dim << i
+            if i > 0:
+                _attach(self, f"layers.{i}.downsample.norm", nn.LayerNorm(2 * c))        # 4 * (c / 2)
+                _attach(self, f"layers.{i}.downsample.reduction", nn.Linear(2 * c, c, bias=False))
+            for j in range(nb):
+                p = f"layers.{i}.blocks.{j}"
+                _attach(self, p + ".norm1", nn.LayerNorm(c))
+                _attach(self, p + ".attn.qkv", nn.Linear(c, 3 * c))
+                _attach(self, p + ".attn.proj", nn.Linear(c, c))
+                _attach(self, p + ".norm2", nn.LayerNorm(c))
+                _attach(self, p + ".mlp.fc1", nn.Linear(c, int(c * mlp_ratio)))
+                _attach(self, p + ".mlp.fc2", nn.Linear(int(c * mlp_ratio), c))
+                name = p.replace(".", "__") + "__attn__rpbt"
+                self.register_parameter(name, nn.Parameter(torch.zeros((2 * window_size - 1) ** 2, self.num_heads[i])))
+                self._tables.append((name, p + ".attn.relative_position_bias_table"))
+        _attach(self, "norm", nn.LayerNorm(embed_dim << (len(self.depths) - 1)))
+        _attach(self, "head.fc", nn.Linear(embed_dim << (len(self.depths) - 1), num_classes))
+        self._packed, self._engines = {}, {}
+
+    def state_dict(self, *a, **k):
+        sd = super().state_dict(*a, **k)
+        ren = dict(self._tables)
+        return type(sd)((ren.get(kk, kk), v) for kk, v in sd.items())
+
+    def load_state_dict(self, sd, strict=True, **k):
+        sd = swin_canonical_state_dict(sd, self.depths)
+        back = {pub: priv for priv, pub in self._tables}
+        return super().load_state_dict({back.get(kk, kk): v for kk, v in sd.items()}, strict=strict, **k)
+
+    def _version(self):
+        dev = next(self.parameters()).device
+        return (str(dev), sum(p._version for p in self.parameters()))
+
+    def _stage_geometry(self):
+        """(resolution, window, shift) per stage: the window shrinks to the map and the shift vanishes when the map is
+        not larger than the window (SwinTransformerBlock / HF set_shift_and_window_size)."""
+        res = self.image_size // self.patch_size
+        out = []
+        for i in range(len(self.depths)):
+            win = min(self.window_size, res)
+            out.append((res, win, 0 if res <= self.window_size else self.window_size // 2))
+            res //= 2
+        return out
+
+    def _bias(self, table, heads, res, win, shift, dev):
+        """[nW or 1][heads][win^2][win^2] f32 in units of log2(e): relative position bias (+ the mask of each window
+        position for shifted blocks: pixels of different wrap-around regions must not attend to each other)."""
+        if table.shape[0] != (2 * win - 1) ** 2:
+            raise ValueError(f"relative_position_bias_table has {table.shape[0]} rows, window {win} needs {(2 * win - 1) ** 2}")
+        co = torch.stack(torch.meshgrid(torch.arange(win), torch.arange(win), indexing="ij")).flatten(1)      # 2, win^2
+        rel = (co[:, :, None] - co[:, None, :]).permute(1, 2, 0) + (win - 1)
+        idx = rel[..., 0] * (2 * win - 1) + rel[..., 1]
+        bias = table.float().cpu()[idx.reshape(-1)].reshape(win * win, win * win, heads).permute(2, 0, 1)[None]   # 1, heads, n, n
+        if shift > 0:
+            reg = lambda n: (torch.arange(n) >= n - win).long() + (torch.arange(n) >= n - shift).long()
+            img = reg(res)[:, None] * 3 + reg(res)[None, :]                                                   # res x res region ids
+            mw = img.reshape(res // win, win, res // win, win).permute(0, 2, 1, 3).reshape(-1, win * win)   # nW, n
+            mask = (mw[:, None, :] != mw[:, :, None]).float() * -100.0                                        # nW, n, n
+            bias = bias + mask[:, None]
+        return (bias * 1.4426950408889634).contiguous().to(dev)
+
+    def packed_weights(self, dt):
+        ver = self._version()
+        hit = self._packed.get(dt)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise _lib.AdvsError(f"SwinVictim parameters are on {dev}: move the model to the GPU; there is no CPU fallback")
+        sd = {k: v.detach() for k, v in self.state_dict().items()}
+        f32 = lambda k: sd[k].float().contiguous()
+        lin = lambda k: pack_conv_weight(sd[k].float().reshape(sd[k].shape[0], -1, 1, 1), dt)
+        W = {"pe.w": lin("patch_embed.proj.weight"), "pe.b": f32("patch_embed.proj.bias"),
+             "pe.g": f32("patch_embed.norm.weight"), "pe.beta": f32("patch_embed.norm.bias")}
+        geo = self._stage_geometry()
+        for i, nb in enumerate(self.depths):
+            c = self.embed_dim << i
+            res, win, shift = geo[i]
+            if i > 0:
+                p = f"layers.{i}.downsample"
+                cp = c // 2                                          # channels before merging
+                # timm / HF concatenate [x(0,0), x(1,0), x(0,1), x(1,1)] (dy, dx); advs_space_to_depth2 emits (0,0),(0,1),(1,0),(1,1)
+                perm = torch.cat([torch.arange(cp) + blk * cp for blk in (0, 2, 1, 3)]).to(dev)
+                W[p + ".g"], W[p + ".beta"] = f32(p + ".norm.weight")[perm].contiguous(), f32(p + ".norm.bias")[perm].contiguous()
+                W[p + ".w"] = pack_conv_weight(sd[p + ".reduction.weight"].float()[:, perm].reshape(c, 4 * cp, 1, 1), dt)
+            for j in range(nb):
+                p = f"layers.{i}.blocks.{j}"
+                for n in ("norm1", "norm2"):
+                    W[f"{p}.{n}.g"], W[f"{p}.{n}.beta"] = f32(f"{p}.{n}.weight"), f32(f"{p}.{n}.bias")
+                for src, dst in ((".attn.qkv", ".qkv"), (".attn.proj", ".proj"), (".mlp.fc1", ".fc1"), (".mlp.fc2", ".fc2")):
+                    W[p + dst + ".w"], W[p + dst + ".b"] = lin(p + src + ".weight"), f32(p + src + ".bias")
+                W[p + ".bias"] = self._bias(sd[p + ".attn.relative_position_bias_table"], self.num_heads[i], res, win,
+                                            shift if j % 2 else 0, dev)
+        W["norm.g"], W["norm.beta"] = f32("norm.weight"), f32("norm.bias")
+        W["head.w"], W["head.b"] = f32("head.fc.weight"), f32("head.fc.bias")
+        self._packed[dt] = (ver, W)
+        for key in [k for k in self._engines if k[1] == dt]:
+            del self._engines[key]
+        return W
+
+    def engine(self, batch, dtype=None):
+        dt = dtype_code(dtype if dtype is not None else self.compute_dtype)
+        W = self.packed_weights(dt)
+        eng = self._engines.get((batch, dt))
+        if eng is None:
+            eng = _SwinEngine(self, W, batch, dt)
+            self._engines[(batch, dt)] = eng
+        return eng
+
+    def forward(self, x):
+        if x.shape[2] != self.image_size or x.shape[3] != self.image_size:
+            raise ValueError(f"SwinVictim was built for {self.image_size}x{self.image_size} inputs, got {tuple(x.shape[2:])}")
+        eng = self.engine(x.shape[0])
+        cur = torch.cuda.current_stream(x.device)
+        eng.stream.wait_stream(cur)
+        with torch.cuda.stream(eng.stream):
+            eng.x.copy_(x.to(torch.float32), non_blocking=True)
+            eng.run()
+            out = eng.logits.clone()
+        cur.wait_stream(eng.stream)
+        out.record_stream(cur)
+        return out
+
+
+class _SwinEngine:
+    def __init__(self, model, W, batch, dt):
+        dev = next(model.parameters()).device
+        self.model, self.stream = model, torch.cuda.Stream(device=dev)
+        S, ps = model.image_size, model.patch_size
+        geo = model._stage_geometry()
+        for res, win, _ in geo:
+            if res % win:
+                raise ValueError(f"SwinVictim: a {res}x{res} map is not a whole number of {win}-pixel windows")
+        with torch.cuda.device(dev):
+            bld = Builder(dev, dt, self.stream, batch)
+            lib = bld.lib
+            self.x = torch.zeros((batch, 3, S, S), dtype=torch.float32, device=dev)
+            g = S // ps
+            patches = bld.buf((batch, g, g, 3 * ps * ps))
+            bld.plan.add(lib.advs_patchify, ptr(self.x), ptr(patches), batch, 3, S, S, ps, dt, keep=(self.x, patches))
+            e = bld.conv(patches, W["pe.w"], model.embed_dim, bias=W["pe.b"], ksize=1, pad=0)
+            bld.free(patches)
+            h = bld.layernorm(e, W["pe.g"], W["pe.beta"], 1e-5)
+            bld.free(e)
+            for i, nb in enumerate(model.depths):
+                c = model.embed_dim << i
+                res, win, shift = geo[i]
+                heads = model.num_heads[i]
+                d = c // heads
+                if i > 0:
+                    p = f"layers.{i}.downsample"
+                    s2d = bld.buf((batch, res, res, 2 * c))
+                    bld.plan.add(lib.advs_space_to_depth2, ptr(h), ptr(s2d), batch, 2 * res, 2 * res, c // 2, dt, keep=(h, s2d))
+                    bld.free(h)
+                    ln = bld.layernorm(s2d, W[p + ".g"], W[p + ".beta"], 1e-5)
+                    bld.free(s2d)
+                    h = bld.conv(ln, W[p + ".w"], c, ksize=1, pad=0)
+                    bld.free(ln)
+                nW = (res // win) ** 2
+                for j in range(nb):
+                    p = f"layers.{i}.blocks.{j}"
+                    sh = shift if j % 2 else 0
+                    ln = bld.layernorm(h, W[p + ".norm1.g"], W[p + ".norm1.beta"], 1e-5)
+                    wins = bld.window_shift(ln, win, sh)
+                    bld.free(ln)
+                    qkv = bld.conv(wins, W[p + ".qkv.w"], 3 * c, bias=W[p + ".qkv.b"], ksize=1, pad=0)
+                    bld.free(wins)
+                    att = bld.attention_bias(qkv, heads, d, 0, c, 2 * c, d, W[p + ".bias"], nW if sh else 1)
+                    bld.free(qkv)
+                    pr = bld.conv(att, W[p + ".proj.w"], c, bias=W[p + ".proj.b"], ksize=1, pad=0)
+                    bld.free(att)
+                    a = bld.window_shift(pr, win, sh, inverse=True, residual=h, image_hw=(res, res))
+                    bld.free(pr)
+                    bld.free(h)
+                    ln = bld.layernorm(a, W[p + ".norm2.g"], W[p + ".norm2.beta"], 1e-5)
+                    f = bld.conv(ln, W[p + ".fc1.w"], W[p + ".fc1.b"].numel(), bias=W[p + ".fc1.b"], act="gelu", ksize=1, pad=0)
+                    bld.free(ln)
+                    h = bld.conv(f, W[p + ".fc2.w"], c, bias=W[p + ".fc2.b"], residual=a, ksize=1, pad=0)
+                    bld.free(f)
+                    bld.free(a)
+            ln = bld.layernorm(h, W["norm.g"], W["norm.beta"], 1e-5)
+            bld.free(h)
+            cl = model.embed_dim << (len(model.depths) - 1)
+            rl = geo[-1][0]
+            pooled = bld.buf((batch, cl), torch.float32)
+            bld.plan.add(lib.advs_global_avgpool, ptr(ln), ptr(pooled), batch, rl * rl, cl, dt, keep=(ln, pooled))
+            self.logits = bld.linear(pooled, W["head.w"], W["head.b"])
+            self.plan, self.captured = bld.plan, False
+            torch.cuda.synchronize(dev)
+
+    def run(self):
+        if self.model.use_graph and not self.captured:
+            self.plan.run_eager()
+            self.stream.synchronize()
+            self.plan.capture()
+            self.captured = True
+        self.plan.run()

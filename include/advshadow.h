@@ -161,6 +161,18 @@ int advs_attention(const void* qkv, void* out, int b, int n, int heads, int d, i
 int advs_attention_masked(const void* qkv, void* out, int b, int n, int n_valid, int heads, int d, int ld,
                           int q_off, int k_off, int v_off, int head_stride, int dtype, void* stream);
 
+/* softmax(q k^T / sqrt(d) + bias) v: bias is f32 [bias_mod][heads][n][n] ALREADY MULTIPLIED BY log2(e); sequence i
+ * uses block i % bias_mod.  Swin's window attention: relative position bias (+ the shifted-window mask of window
+ * position i % nW) -- timm swin_base_patch4_window7_224 (ASR_fast.py:27-32).                                    */
+int advs_attention_bias(const void* qkv, void* out, const float* bias_log2e, int bias_mod, int b, int n,
+                        int heads, int d, int ld, int q_off, int k_off, int v_off, int head_stride, int dtype,
+                        void* stream);
+/* Swin's cyclic shift + window partition as one gather, and its inverse (+ the block's residual):
+ * image side [b][h][w][c], window side [b*(h/window)*(w/window)][window*window][c]; token (ty,tx) of window (wy,wx)
+ * is pixel ((wy*window+ty+shift) % h, (wx*window+tx+shift) % w).  inverse: y[pixel] = x[token] + residual[pixel].  */
+int advs_window_shift(const void* x, const void* residual, void* y, int b, int h, int w, int c, int window,
+                      int shift, int inverse, int dtype, void* stream);
+
 /* ---- small dense layers of the time-embedding path (always f32) ------------------------
  * y[b][n] = bias[n] + sum_k act_in(x[b][k]) * w[n][k]   (nn.Linear after optional SiLU:
  * diff_model.py:184-188,77-80; model/modules/block.py:33-36).  w is torch layout [n][k].     */

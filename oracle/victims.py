@@ -97,3 +97,21 @@ def hf_convnext(num_labels=37, seed=5, **cfg):
             elif n.endswith("bias"):
                 p.copy_(torch.randn_like(p) * 0.05)
     return m
+
+
+def hf_swin(num_labels=37, seed=7, **cfg):
+    """The installed transformers SwinForImageClassification, random init with non-trivial relative position bias
+    tables: the Swin victim's oracle.  The reference loads ``timm.create_model('swin_base_patch4_window7_224')``
+    (ASR_fast.py:27-32); timm is absent, the architecture is the same, parameter names differ (the product maps)."""
+    from transformers import SwinConfig, SwinForImageClassification
+    torch.manual_seed(seed)
+    m = SwinForImageClassification(SwinConfig(num_labels=num_labels, **cfg)).eval()
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if n.endswith("relative_position_bias_table"):
+                p.copy_(torch.randn_like(p) * 0.5)
+            elif "layernorm" in n or n.endswith("norm.weight") or n.endswith("norm.bias"):
+                p.copy_(torch.randn_like(p) * 0.1 + (1.0 if n.endswith("weight") else 0.0))
+            elif n.endswith("bias"):
+                p.copy_(torch.randn_like(p) * 0.05)
+    return m

@@ -194,3 +194,68 @@ def test_convnext_base_top1_vs_hf():
     assert torch.equal(got.argmax(1), ref.argmax(1))
     pred = asr.evaluate_batch((x * 255).to(torch.uint8).cuda(), net)           # plugs into the ASR path like any victim
     assert pred.shape == (2,)
+
+
+# ------------------------------------------------------------------------------ Swin (ASR_fast.py:27-32)
+def test_swin_small_config_matches_hf_transformers():
+    """A small Swin (embed 32, depths 2-2, heads 2-4, window 4, 64 px: shifted windows with masks in stage 1,
+    whole-map windows in stage 2, one patch merging) against the installed transformers implementation."""
+    from advshadow_amd.victims import SwinVictim
+    cfg = dict(image_size=64, patch_size=4, embed_dim=32, depths=[2, 2], num_heads=[2, 4], window_size=4)
+    hf = ov.hf_swin(7, seed=7, **cfg)
+    x = torch.rand(3, 3, 64, 64, generator=torch.Generator().manual_seed(12))
+    with torch.no_grad():
+        ref = hf(pixel_values=x).logits
+    scale = max(1.0, ref.abs().max().item())
+    for dt, bound in (("fp32", 3e-4), ("fp16", 0.02), ("bf16", 0.08)):
+        net = SwinVictim(7, embed_dim=32, depths=[2, 2], num_heads=[2, 4], window_size=4, image_size=64, compute_dtype=dt)
+        net.load_state_dict(hf.state_dict())
+        net = net.to("cuda").eval()
+        for _ in range(2):
+            got = net(x.cuda()).cpu()
+            assert (got - ref).abs().max().item() < bound * scale, (dt, (got - ref).abs().max().item())
+        if dt == "fp32":
+            assert torch.equal(got.argmax(1), ref.argmax(1))
+
+
+def test_swin_base_top1_vs_hf():
+    """swin_base_patch4_window7_224 geometry: embed 128, depths 2-2-18-2, heads 4-8-16-32, window 7, 49-token windows."""
+    from advshadow_amd.victims import SwinVictim
+    hf = ov.hf_swin(37, seed=8, embed_dim=128, depths=[2, 2, 18, 2], num_heads=[4, 8, 16, 32], window_size=7)
+    x = torch.rand(2, 3, 224, 224, generator=torch.Generator().manual_seed(13))
+    with torch.no_grad():
+        ref = hf(pixel_values=x).logits
+    net = SwinVictim(37)
+    net.load_state_dict(hf.state_dict())
+    got = net.to("cuda").eval()(x.cuda()).cpu()
+    assert (got - ref).abs().max().item() < 1e-3 * max(1.0, ref.abs().max().item())
+    assert torch.equal(got.argmax(1), ref.argmax(1))
+
+
+def test_window_shift_roundtrip_and_bias_attention():
+    """advs_window_shift forward == roll(-s) + window_partition; inverse restores the image (+ residual);
+    advs_attention_bias == softmax(qk^T/sqrt(d) + bias) v with per-window bias blocks."""
+    import math
+    B, H, W, C, win, sh = 2, 8, 12, 32, 4, 2
+    g = torch.Generator().manual_seed(14)
+    x = torch.randn(B, H, W, C, generator=g)
+    op = OneOp("fp32", B)
+    wins = op.b.window_shift(x.to(dev()), win, sh)
+    back = op.b.window_shift(wins, win, sh, inverse=True, residual=x.to(dev()), image_hw=(H, W))
+    op.go()
+    rolled = torch.roll(x, shifts=(-sh, -sh), dims=(1, 2))
+    ref = rolled.view(B, H // win, win, W // win, win, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, win * win, C)
+    assert torch.equal(wins.cpu().view(-1, win * win, C), ref)
+    assert torch.equal(back.cpu(), 2 * x)
+    nW, heads, d, N = 6, 2, 16, 16
+    qkv = torch.randn(B * nW, N, 3 * heads * d, generator=g)
+    bias = torch.randn(nW, heads, N, N, generator=g)
+    t = qkv.view(B * nW, N, 3, heads, d)
+    q, k, v = (t[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    sc = q @ k.transpose(-1, -2) / math.sqrt(d) + bias.repeat(B, 1, 1, 1)
+    refa = (torch.softmax(sc, -1) @ v).permute(0, 2, 1, 3).reshape(B * nW, N, heads * d)
+    op = OneOp("fp32", B * nW)
+    y = op.b.attention_bias(qkv.view(B * nW, 1, N, -1).to(dev()), heads, d, 0, heads * d, 2 * heads * d, d,
+                            (bias * 1.4426950408889634).contiguous().to(dev()), nW)
+    op.go()
+    assert (y.cpu().view(B * nW, N, heads * d) - refa).abs().max().item() < 2e-5
