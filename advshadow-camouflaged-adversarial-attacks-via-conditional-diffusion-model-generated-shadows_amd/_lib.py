@@ -49,9 +49,11 @@ SIGNATURES = {
     "advs_attention_masked": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "advs_attention_bias": [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "advs_window_shift": [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "advs_cls_mean_rows_f32": [vp, vp, i32, i32, i32, i32, i32, vp],
     "advs_dwconv2d": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "advs_space_to_depth2": [vp, vp, i32, i32, i32, i32, i32, vp],
     "advs_patchify": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "advs_patchify_padded": [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "advs_vit_assemble": [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "advs_gather_rows_f32": [vp, vp, i32, C.c_longlong, i32, i32, vp],
     "advs_attention": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],

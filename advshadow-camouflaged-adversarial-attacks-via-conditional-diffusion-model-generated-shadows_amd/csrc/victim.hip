@@ -146,12 +146,13 @@ extern "C" int advs_global_avgpool(const void* x, float* y, int b, int hw, int c
 // patch-embedding Conv2d(cin, hidden, ps, stride ps) weight viewed as [hidden][cin*ps*ps]; the projection itself
 // is then an advs_conv2d 1x1.
 template <typename T>
-__global__ void patchify_kernel(const float* __restrict__ x, T* __restrict__ y, int B, int Cin, int H, int W, int ps) {
-    const int gh = H / ps, gw = W / ps, K = Cin * ps * ps;
-    const size_t total = (size_t)B * gh * gw * K;
+__global__ void patchify_kernel(const float* __restrict__ x, T* __restrict__ y, int B, int Cin, int H, int W, int ps, int Kp) {
+    const int gh = H / ps, gw = W / ps, K = Cin * ps * ps;         // rows are Kp >= K long, zero beyond K
+    const size_t total = (size_t)B * gh * gw * Kp;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int k = (int)(i % K);
-        size_t r = i / K;
+        const int k = (int)(i % Kp);
+        size_t r = i / Kp;
+        if (k >= K) { Elt<T>::st(y + i, 0.f); continue; }
         const int px = (int)(r % gw); r /= gw;
         const int py = (int)(r % gh);
         const int b = (int)(r / gh);
@@ -159,14 +160,19 @@ __global__ void patchify_kernel(const float* __restrict__ x, T* __restrict__ y, 
         Elt<T>::st(y + i, x[(((size_t)b * Cin + c) * H + py * ps + ky) * W + px * ps + kx]);
     }
 }
-extern "C" int advs_patchify(const float* x_nchw, void* y, int b, int cin, int h, int w, int patch, int dtype, void* stream) {
+extern "C" int advs_patchify_padded(const float* x_nchw, void* y, int b, int cin, int h, int w, int patch, int kpad, int dtype,
+                                    void* stream) {
     ADVS_REQUIRE(dtype_ok(dtype), "advs_patchify: unknown dtype code %d", dtype);
     ADVS_REQUIRE(x_nchw && y && b > 0 && cin > 0 && patch > 0 && h % patch == 0 && w % patch == 0, "patchify: bad args");
-    const size_t total = (size_t)b * cin * h * w;
+    ADVS_REQUIRE(kpad >= cin * patch * patch, "patchify: row length %d shorter than the %d patch elements", kpad, cin * patch * patch);
+    const size_t total = (size_t)b * (h / patch) * (w / patch) * kpad;
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    ADVS_SWITCH_T(dtype, patchify_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>(x_nchw, (T*)y, b, cin, h, w, patch));
+    ADVS_SWITCH_T(dtype, patchify_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>(x_nchw, (T*)y, b, cin, h, w, patch, kpad));
     ADVS_CHECK_LAUNCH("patchify");
     return ADVS_OK;
+}
+extern "C" int advs_patchify(const float* x_nchw, void* y, int b, int cin, int h, int w, int patch, int dtype, void* stream) {
+    return advs_patchify_padded(x_nchw, y, b, cin, h, w, patch, cin * patch * patch, dtype, stream);
 }
 
 // tokens[b][0] = cls + pos[0]; tokens[b][1+i] = patches[b][i] + pos[1+i]; rows >= 1+np are zero padding
@@ -350,5 +356,32 @@ extern "C" int advs_window_shift(const void* x, const void* residual, void* y, i
     const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     ADVS_SWITCH_T(dtype, window_shift_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T*)x, (const T*)residual, (T*)y, b, h, w, c, window, shift, inverse));
     ADVS_CHECK_LAUNCH("window_shift");
+    return ADVS_OK;
+}
+
+// DINOv2 classifier input (Dinov2ForImageClassification.forward): y[b] = [ tokens[b][0] | mean(tokens[b][1 .. np]) ],
+// tokens [B][n_pad][C] T -> y [B][2C] f32.  One workgroup per (64 channels, sample).
+template <typename T>
+__global__ void __launch_bounds__(256)
+cls_mean_rows_kernel(const T* __restrict__ x, float* __restrict__ y, int n_pad, int np, int C) {
+    __shared__ float part[256];
+    const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    const T* xb = x + (size_t)b * n_pad * C;
+    float s = 0.f;
+    if (c < C)
+        for (int r = 1 + q; r <= np; r += 4) s += Elt<T>::ld(xb + (size_t)r * C + c);
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (q == 0 && c < C) {
+        y[(size_t)b * 2 * C + c] = Elt<T>::ld(xb + c);
+        y[(size_t)b * 2 * C + C + c] = (part[threadIdx.x] + part[threadIdx.x + 64] + part[threadIdx.x + 128] + part[threadIdx.x + 192]) / (float)np;
+    }
+}
+extern "C" int advs_cls_mean_rows_f32(const void* tokens, float* y, int b, int n_pad, int np, int c, int dtype, void* stream) {
+    ADVS_REQUIRE(dtype_ok(dtype), "advs_cls_mean_rows_f32: unknown dtype code %d", dtype);
+    ADVS_REQUIRE(tokens && y && b > 0 && np > 0 && np < n_pad && c > 0, "cls_mean_rows: bad args");
+    dim3 grid(cdiv(c, 64), b);
+    ADVS_SWITCH_T(dtype, cls_mean_rows_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T*)tokens, y, n_pad, np, c));
+    ADVS_CHECK_LAUNCH("cls_mean_rows");
     return ADVS_OK;
 }

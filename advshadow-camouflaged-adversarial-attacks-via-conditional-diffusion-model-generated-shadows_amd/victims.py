@@ -177,6 +177,17 @@ def vit_canonical_state_dict(sd):
     return out
 
 
+def _patch_proj(w, dt):
+    """Patch-embedding Conv2d weight [C, 3, ps, ps] as a GEMM weight whose K is padded with zeros to the row length
+    advs_patchify_padded produces (a multiple of 64 elements in every dtype)."""
+    w2 = w.detach().float().reshape(w.shape[0], -1)
+    k = w2.shape[1]
+    kpad = -(-k // 64) * 64
+    if kpad != k:
+        w2 = torch.nn.functional.pad(w2, (0, kpad - k))
+    return pack_conv_weight(w2.reshape(w2.shape[0], kpad, 1, 1), dt)
+
+
 class ViTVictim(nn.Module):
     """ViT-B/16-style classifier with HF's parameter names (``AutoModelForImageClassification`` of
     ASR_fast.py:47-51; config C4 of BASELINE.json), forward on the HIP kernels: patch projection and every
@@ -232,7 +243,7 @@ class ViTVictim(nn.Module):
         f32 = lambda k: sd[k].float().contiguous()
         lin = lambda k: pack_conv_weight(sd[k].float().reshape(sd[k].shape[0], -1, 1, 1), dt)
         W = {"cls": f32("vit.embeddings.cls_token").reshape(-1), "pos": f32("vit.embeddings.position_embeddings")[0].contiguous(),
-             "proj.w": lin("vit.embeddings.patch_embeddings.projection.weight"),
+             "proj.w": _patch_proj(sd["vit.embeddings.patch_embeddings.projection.weight"], dt),
              "proj.b": f32("vit.embeddings.patch_embeddings.projection.bias")}
         for i in range(self.cfg["layers"]):
             p = f"vit.encoder.layer.{i}"
@@ -288,8 +299,9 @@ class _ViTEngine:
             bld = Builder(dev, dt, self.stream, batch)
             lib = bld.lib
             self.x = torch.zeros((batch, 3, S, S), dtype=torch.float32, device=dev)
-            patches = bld.buf((batch, g, g, 3 * ps * ps))
-            bld.plan.add(lib.advs_patchify, ptr(self.x), ptr(patches), batch, 3, S, S, ps, dt, keep=(self.x, patches))
+            kpad = -(-3 * ps * ps // 64) * 64              # whole 128-byte slabs in every dtype (14x14 patches: 588 -> 640)
+            patches = bld.buf((batch, g, g, kpad))
+            bld.plan.add(lib.advs_patchify_padded, ptr(self.x), ptr(patches), batch, 3, S, S, ps, kpad, dt, keep=(self.x, patches))
             emb = bld.conv(patches, W["proj.w"], C, bias=W["proj.b"], ksize=1, pad=0)
             bld.free(patches)
             tok = bld.buf((batch, 1, n_pad, C))
@@ -314,8 +326,12 @@ class _ViTEngine:
                 bld.free(h)
             ln = bld.layernorm(tok, W["ln.g"], W["ln.b"], eps)
             bld.free(tok)
-            cls = bld.buf((batch, C), torch.float32)
-            bld.plan.add(lib.advs_gather_rows_f32, ptr(ln), ptr(cls), batch, n_pad, C, dt, keep=(ln, cls))
+            if cfg.get("head") == "cls_mean":          # DINOv2: Linear on [cls | mean of the patch tokens]
+                cls = bld.buf((batch, 2 * C), torch.float32)
+                bld.plan.add(lib.advs_cls_mean_rows_f32, ptr(ln), ptr(cls), batch, n_pad, npatch, C, dt, keep=(ln, cls))
+            else:
+                cls = bld.buf((batch, C), torch.float32)
+                bld.plan.add(lib.advs_gather_rows_f32, ptr(ln), ptr(cls), batch, n_pad, C, dt, keep=(ln, cls))
             self.logits = bld.linear(cls, W["cls.w"], W["cls.b"])
             self.plan, self.captured = bld.plan, False
             torch.cuda.synchronize(dev)
@@ -877,3 +893,104 @@ class _SwinEngine:
             self.plan.capture()
             self.captured = True
         self.plan.run()
+
+
+
+# ============================================================================ DINOv2 (HF names)
+class Dinov2Victim(nn.Module):
+    """HF ``Dinov2ForImageClassification`` (the other ``AutoModelForImageClassification`` checkpoint family of
+    ASR_fast.py:47-58) on the ViT engine: patch 14, LayerScale after attention and MLP (folded into the projection /
+    fc2 weights), position embeddings interpolated bicubically on the host when the checkpoint's grid differs from the
+    input's (Dinov2Embeddings.interpolate_pos_encoding), classifier on [cls | mean of the patch tokens].
+    The SwiGLU feed-forward of the giant variant is not built."""
+
+    def __init__(self, num_labels=37, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, mlp_ratio=4,
+                 patch_size=14, image_size=224, pos_grid=None, layer_norm_eps=1e-6, compute_dtype="fp32", use_graph=True):
+        super().__init__()
+        if image_size % patch_size:
+            raise ValueError("Dinov2Victim: image_size must be a multiple of patch_size")
+        grid = pos_grid or image_size // patch_size          # pos_grid: the grid the checkpoint was trained with (e.g. 37)
+        self.cfg = dict(num_labels=num_labels, hidden=hidden_size, layers=num_hidden_layers, heads=num_attention_heads,
+                        mlp=hidden_size * mlp_ratio, patch=patch_size, image=image_size, eps=layer_norm_eps, head="cls_mean")
+        self.pos_grid, self.compute_dtype, self.use_graph = grid, compute_dtype, use_graph
+        C = hidden_size
+        emb = nn.Module()
+        emb.cls_token = nn.Parameter(torch.randn(1, 1, C) * 0.02)
+        emb.mask_token = nn.Parameter(torch.zeros(1, C))
+        emb.position_embeddings = nn.Parameter(torch.randn(1, grid * grid + 1, C) * 0.02)
+        _attach(self, "dinov2.embeddings", emb)
+        _attach(self, "dinov2.embeddings.patch_embeddings.projection", nn.Conv2d(3, C, patch_size, stride=patch_size))
+        for i in range(num_hidden_layers):
+            p = f"dinov2.encoder.layer.{i}"
+            _attach(self, p + ".norm1", nn.LayerNorm(C, eps=layer_norm_eps))
+            for n in ("query", "key", "value"):
+                _attach(self, f"{p}.attention.attention.{n}", nn.Linear(C, C))
+            _attach(self, p + ".attention.output.dense", nn.Linear(C, C))
+            for k in (1, 2):
+                ls = nn.Module()
+                ls.lambda1 = nn.Parameter(torch.ones(C))
+                _attach(self, f"{p}.layer_scale{k}", ls)
+            _attach(self, p + ".norm2", nn.LayerNorm(C, eps=layer_norm_eps))
+            _attach(self, p + ".mlp.fc1", nn.Linear(C, C * mlp_ratio))
+            _attach(self, p + ".mlp.fc2", nn.Linear(C * mlp_ratio, C))
+        _attach(self, "dinov2.layernorm", nn.LayerNorm(C, eps=layer_norm_eps))
+        _attach(self, "classifier", nn.Linear(2 * C, num_labels))
+        self._packed, self._engines = {}, {}
+
+    def _version(self):
+        return (str(next(self.parameters()).device), sum(p._version for p in self.parameters()))
+
+    def _pos(self, pe):
+        """Dinov2Embeddings.interpolate_pos_encoding on the host (bicubic, align_corners=False), once per weight set."""
+        g_in, g_out = self.pos_grid, self.cfg["image"] // self.cfg["patch"]
+        if g_in == g_out:
+            return pe[0].float().contiguous()
+        C = pe.shape[-1]
+        patch = pe[:, 1:].float().reshape(1, g_in, g_in, C).permute(0, 3, 1, 2)
+        patch = torch.nn.functional.interpolate(patch, size=(g_out, g_out), mode="bicubic", align_corners=False)
+        return torch.cat([pe[0, :1].float(), patch.permute(0, 2, 3, 1).reshape(-1, C)], 0).contiguous()
+
+    def packed_weights(self, dt):
+        ver = self._version()
+        hit = self._packed.get(dt)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise _lib.AdvsError(f"Dinov2Victim parameters are on {dev}: move the model to the GPU; there is no CPU fallback")
+        sd = {k: v.detach() for k, v in self.state_dict().items()}
+        f32 = lambda k: sd[k].float().contiguous()
+        lin = lambda w: pack_conv_weight(w.float().reshape(w.shape[0], -1, 1, 1), dt)
+        W = {"cls": f32("dinov2.embeddings.cls_token").reshape(-1), "pos": self._pos(sd["dinov2.embeddings.position_embeddings"]),
+             "proj.w": _patch_proj(sd["dinov2.embeddings.patch_embeddings.projection.weight"], dt),
+             "proj.b": f32("dinov2.embeddings.patch_embeddings.projection.bias")}
+        for i in range(self.cfg["layers"]):
+            s, p = f"dinov2.encoder.layer.{i}", f"vit.encoder.layer.{i}"            # the ViT engine's key scheme
+            a = s + ".attention.attention."
+            W[p + ".qkv.w"] = lin(torch.cat([sd[a + n + ".weight"] for n in ("query", "key", "value")], 0))
+            W[p + ".qkv.b"] = torch.cat([sd[a + n + ".bias"].float() for n in ("query", "key", "value")], 0).contiguous()
+            l1, l2 = sd[s + ".layer_scale1.lambda1"].float(), sd[s + ".layer_scale2.lambda1"].float()
+            W[p + ".o.w"] = lin(sd[s + ".attention.output.dense.weight"].float() * l1[:, None])
+            W[p + ".o.b"] = (sd[s + ".attention.output.dense.bias"].float() * l1).contiguous()
+            W[p + ".fc1.w"], W[p + ".fc1.b"] = lin(sd[s + ".mlp.fc1.weight"]), f32(s + ".mlp.fc1.bias")
+            W[p + ".fc2.w"] = lin(sd[s + ".mlp.fc2.weight"].float() * l2[:, None])
+            W[p + ".fc2.b"] = (sd[s + ".mlp.fc2.bias"].float() * l2).contiguous()
+            for src, dst in ((".norm1", ".layernorm_before"), (".norm2", ".layernorm_after")):
+                W[p + dst + ".g"], W[p + dst + ".b"] = f32(s + src + ".weight"), f32(s + src + ".bias")
+        W["ln.g"], W["ln.b"] = f32("dinov2.layernorm.weight"), f32("dinov2.layernorm.bias")
+        W["cls.w"], W["cls.b"] = f32("classifier.weight"), f32("classifier.bias")
+        self._packed[dt] = (ver, W)
+        for key in [k for k in self._engines if k[1] == dt]:
+            del self._engines[key]
+        return W
+
+    def engine(self, batch, dtype=None):
+        dt = dtype_code(dtype if dtype is not None else self.compute_dtype)
+        W = self.packed_weights(dt)
+        eng = self._engines.get((batch, dt))
+        if eng is None:
+            eng = _ViTEngine(self, W, batch, dt)
+            self._engines[(batch, dt)] = eng
+        return eng
+
+    forward = ViTVictim.forward

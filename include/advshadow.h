@@ -274,6 +274,10 @@ int advs_conv_stem(const float* x_nchw, const float* w_oihw, const float* bias, 
 int advs_maxpool3x3s2(const void* x, void* y, int b, int h, int w, int c, int dtype, void* stream); /* MaxPool2d(3,2,1) */
 int advs_global_avgpool(const void* x, float* y, int b, int hw, int c, int dtype, void* stream);    /* -> f32 [b][c] */
 
+/* DINOv2's classifier input (Dinov2ForImageClassification.forward; HF checkpoints of ASR_fast.py:47-58):
+ * y[b] = [ tokens[b][0] | mean(tokens[b][1..np]) ], tokens [b][n_pad][c] -> y [b][2c] f32.                        */
+int advs_cls_mean_rows_f32(const void* tokens, float* y, int b, int n_pad, int np, int c, int dtype, void* stream);
+
 /* ---- ConvNeXt victim pieces (timm convnext_base.fb_in1k, ASR_fast.py:21-26) ----------------
  * Depthwise k x k conv (groups = c), stride 1|2, padding k/2, NHWC; w_taps_c is the [c][1][k][k] weight transposed to
  * [k*k][c] f32.  y is [b][ho][wo][c].                                                                          */
@@ -286,6 +290,10 @@ int advs_space_to_depth2(const void* x, void* y, int b, int h, int w, int c, int
  * the patch-embedding conv weight's ([hidden][cin*ps*ps]); tokens = [cls | patches] + position embeddings, rows
  * padded with zeros to n_pad; CLS rows gathered to f32 for the classifier head.                                */
 int advs_patchify(const float* x_nchw, void* y, int b, int cin, int h, int w, int patch, int dtype, void* stream);
+/* Same with rows of kpad >= cin*patch*patch elements, zero beyond the patch: a row length that is a whole number of
+ * 128-byte slabs for any patch size (DINOv2's 14x14 patches are 588 elements = 1176 bytes in the 16-bit modes).   */
+int advs_patchify_padded(const float* x_nchw, void* y, int b, int cin, int h, int w, int patch, int kpad, int dtype,
+                         void* stream);
 int advs_vit_assemble(const void* patches, const float* cls, const float* pos, void* tokens, int b, int np,
                       int n_pad, int c, int dtype, void* stream);
 int advs_gather_rows_f32(const void* x, float* y, int b, long long row_stride, int c, int dtype, void* stream);

@@ -115,3 +115,20 @@ def hf_swin(num_labels=37, seed=7, **cfg):
             elif n.endswith("bias"):
                 p.copy_(torch.randn_like(p) * 0.05)
     return m
+
+
+def hf_dinov2(num_labels=37, seed=9, **cfg):
+    """The installed transformers Dinov2ForImageClassification, random init with non-trivial LayerScale: the DINOv2
+    victim's oracle (the reference loads such checkpoints with AutoModelForImageClassification, ASR_fast.py:47-58)."""
+    from transformers import Dinov2Config, Dinov2ForImageClassification
+    torch.manual_seed(seed)
+    m = Dinov2ForImageClassification(Dinov2Config(num_labels=num_labels, **cfg)).eval()
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if n.endswith("lambda1"):
+                p.copy_(torch.rand_like(p) * 0.8 + 0.2)
+            elif n.endswith("position_embeddings") or n.endswith("cls_token"):
+                p.copy_(torch.randn_like(p) * 0.3)
+            elif n.endswith("bias"):
+                p.copy_(torch.randn_like(p) * 0.05)
+    return m

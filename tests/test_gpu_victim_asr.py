@@ -259,3 +259,25 @@ def test_window_shift_roundtrip_and_bias_attention():
                             (bias * 1.4426950408889634).contiguous().to(dev()), nW)
     op.go()
     assert (y.cpu().view(B * nW, N, heads * d) - refa).abs().max().item() < 2e-5
+
+
+# ------------------------------------------------------------------------------ DINOv2 (ASR_fast.py:47-58)
+def test_dinov2_matches_hf_transformers():
+    """Small DINOv2 (2 layers, 4 heads, patch 14) vs transformers: same-grid position embeddings at 56 px, and a
+    checkpoint grid (4x4) interpolated bicubically to the 8x8 grid of a 112 px input."""
+    from advshadow_amd.victims import Dinov2Victim
+    cfg = dict(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, patch_size=14, mlp_ratio=4)
+    hf = ov.hf_dinov2(5, seed=9, image_size=56, **cfg)
+    for size, dts in ((56, (("fp32", 3e-4), ("fp16", 0.02), ("bf16", 0.08))), (112, (("fp32", 3e-4),))):
+        x = torch.rand(2, 3, size, size, generator=torch.Generator().manual_seed(15))
+        with torch.no_grad():
+            ref = hf(pixel_values=x).logits
+        scale = max(1.0, ref.abs().max().item())
+        for dt, bound in dts:
+            net = Dinov2Victim(5, hidden_size=64, num_hidden_layers=2, num_attention_heads=4, image_size=size, pos_grid=4,
+                               compute_dtype=dt)
+            net.load_state_dict(hf.state_dict())
+            got = net.to("cuda").eval()(x.cuda()).logits.cpu()
+            assert (got - ref).abs().max().item() < bound * scale, (size, dt, (got - ref).abs().max().item())
+            if dt == "fp32":
+                assert torch.equal(got.argmax(1), ref.argmax(1))
