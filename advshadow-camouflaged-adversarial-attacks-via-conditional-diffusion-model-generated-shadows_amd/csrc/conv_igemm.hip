@@ -309,14 +309,14 @@ static int conv_launch(ConvKP& p, hipStream_t st) {
     return ADVS_OK;
 }
 
-static int pick_tile(long long M, int cout);
+static int pick_tile(long long m_img, int cout);
 bool conv_halo_eligible(const ConvKP& p);
 int conv_halo_dispatch(ConvKP& p, int dtype, hipStream_t st);
 int conv_halo_subpixel_dispatch(ConvKP& p, int dtype, hipStream_t st);
 
 template <typename T>
 static int conv_dispatch(ConvKP& p, int tile, hipStream_t st) {
-    if (tile == 0) tile = pick_tile(p.M, p.Cout);
+    if (tile == 0) tile = pick_tile((long long)p.Ho * p.Wo, p.Cout);
     switch (tile) {
         // ILV (DMA issue spread between the MFMA groups) pays when both waves of a SIMD belong to one
         // workgroup and so run in lockstep (8-wave tiles); with two 4-wave workgroups per CU the plain
@@ -337,22 +337,24 @@ static int conv_dispatch(ConvKP& p, int tile, hipStream_t st) {
 static int g_tile_override = 0;
 extern "C" int advs_conv_set_tile(int tile) { g_tile_override = tile; return ADVS_OK; }
 
-static int pick_tile(long long M, int cout) {
+static int pick_tile(long long m_img, int cout) {
     // measured on MI355X (tools/tune_conv.py, round 1): the 256x256 tile wins (~1.05-1.15 vs
-    // ~1.0 PFLOP/s) whenever Cout fills it and M still yields >= 1.5 blocks per CU; the
-    // 128x128 tile at two blocks per CU wins everywhere else, including Cout = 128.
-    const long long blocks256 = (long long)cdiv(M, 256) * cdiv(cout, 256);
-    return (cout % 256 == 0 && blocks256 >= 384) ? 4 : 1;
+    // ~1.0 PFLOP/s) whenever Cout fills it and the launch still yields >= 1.5 blocks per CU at the
+    // headline batch of 32; the 128x128 tile at two blocks per CU wins everywhere else, including Cout = 128.
+    // The rule looks at ONE image's pixels (m_img = Ho*Wo), never at the batch: the tile fixes the order of the
+    // K summation, so an image must get the same tile whichever batch it is evaluated in (batch-shard equality).
+    const long long blocks256 = (long long)cdiv(m_img, 256) * cdiv(cout, 256);
+    return (cout % 256 == 0 && blocks256 >= 12) ? 4 : 1;
 }
 // the 16x16-pixel halo kernel wins wherever it applies (3x3, stride 1, no upsample / extra operand, image a
 // multiple of 16: +15..30 % over the per-tap tiles on every such layer of the eps-predictor, tools/tune_conv.py)
-static int resolve_tile(const advs_conv_args* a, long long M) {
+static int resolve_tile(const advs_conv_args* a, long long m_img) {
     if (a->upsample == ADVS_UPSAMPLE_SUBPIXEL) return 12;       // weights are packed per output parity: one kernel only
     if (g_tile_override) return g_tile_override;
     if (a->tile) return a->tile;
     if (a->ksize == 3 && a->stride == 1 && a->pad == 1 && !a->upsample && !a->e1 && a->h % 16 == 0 && a->w_ % 16 == 0)
         return 10;
-    return pick_tile(M, a->cout);
+    return pick_tile(m_img, a->cout);
 }
 /* tile id advs_conv2d will use for this descriptor, and the row-block height (rows per stats entry) of a tile id */
 extern "C" int advs_conv_resolve_tile(const advs_conv_args* a) {
@@ -360,7 +362,7 @@ extern "C" int advs_conv_resolve_tile(const advs_conv_args* a) {
     const int ups = a->upsample ? 1 : 0;
     const long long ho = (((long long)a->h << ups) + 2 * a->pad - a->ksize) / a->stride + 1;
     const long long wo = (((long long)a->w_ << ups) + 2 * a->pad - a->ksize) / a->stride + 1;
-    return resolve_tile(a, (long long)a->b * ho * wo);
+    return resolve_tile(a, ho * wo);
 }
 extern "C" int advs_conv_tile_rows(int tile) {
     switch (tile) { case 1: case 2: case 5: case 6: case 8: case 10: case 12: return 64; case 3: case 4: case 7: case 9: return 128; default: return 0; }
@@ -416,10 +418,10 @@ extern "C" int advs_conv2d(const advs_conv_args* a, void* stream) {
     p.x1_bytes = (unsigned)x1b; p.x2_bytes = (unsigned)(a->x2 ? x2b : x1b); p.w_bytes = (unsigned)wb;
     p.act = a->act; p.temb_stride = a->temb_stride > 0 ? a->temb_stride : a->cout;
     p.dHoWo.init((unsigned)(p.Ho * p.Wo)); p.dWo.init((unsigned)p.Wo);
-    int tile = resolve_tile(a, M);
+    int tile = resolve_tile(a, (long long)p.Ho * p.Wo);
     if (tile == 10 && !conv_halo_eligible(p)) {
         ADVS_REQUIRE(g_tile_override != 0, "conv2d: tile 10 (halo kernel) needs 3x3 stride 1 pad 1, no upsample / extra operand, H and W multiples of 16");
-        tile = pick_tile(M, a->cout);                       // tuning override on a shape the halo kernel cannot take
+        tile = pick_tile((long long)p.Ho * p.Wo, a->cout);   // tuning override on a shape the halo kernel cannot take
     }
     if (p.stats) {
         const int wm = advs_conv_tile_rows(tile);

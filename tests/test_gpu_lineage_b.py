@@ -147,3 +147,22 @@ def test_p_sample_step_and_device_noise():
     assert np.isfinite(free[0]).all()
     xt = gd.q_sample(x.cuda(), torch.tensor([3, 5], device="cuda"), noise=z.cuda())
     assert xt.shape == x.shape
+
+
+def test_full_size_properties_bf16():
+    """BASELINE config 1 at full size (batch 32, 256x256, bf16, default UNetModel; 4 DDIM steps keep it short):
+    size-independent properties -- replays are bit-identical, outputs are finite and bounded, and an image's trajectory
+    does not depend on the batch it sits in (kernel and tile choices look at one image's shape only; GroupNorm
+    statistics use a fixed number of chunks and no atomics) -- the property batch sharding over GPUs rests on."""
+    from advshadow_amd.diff_model import GaussianDiffusion
+    torch.manual_seed(0)
+    net = UNetModel(compute_dtype="bf16").to("cuda").eval()
+    gd = GaussianDiffusion()
+    g = torch.Generator().manual_seed(1234)
+    xT = torch.randn(32, 3, 256, 256, generator=g)
+    a = gd.ddim_sample(net, 256, batch_size=32, ddim_timesteps=4, x_T=xT, return_tensor=True).clone()
+    b = gd.ddim_sample(net, 256, batch_size=32, ddim_timesteps=4, x_T=xT, return_tensor=True)
+    assert torch.equal(a, b)
+    assert torch.isfinite(a).all() and a.abs().max().item() < 1.5            # x0 is clipped to [-1, 1]; the last step adds sqrt(1 - a_0) eps
+    sub = gd.ddim_sample(net, 256, batch_size=4, ddim_timesteps=4, x_T=xT[8:12], return_tensor=True)
+    assert torch.equal(sub, a[8:12])
