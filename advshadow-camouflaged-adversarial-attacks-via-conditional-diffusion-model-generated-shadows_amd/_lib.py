@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libadvshadow_hip.so")
 
 F32, BF16, F16 = 0, 1, 2
-ACT = {"none": 0, None: 0, "relu": 1, "silu": 2, "gelu": 3, "relu6": 4, "lrelu": 5, "lrelu001": 6}
+ACT = {"none": 0, None: 0, "relu": 1, "silu": 2, "gelu": 3, "relu6": 4, "lrelu": 5, "lrelu001": 6, "sigmoid": 7}
 GN_RESIDUAL_AFTER_ACT = 0x100      # include/advshadow.h
 
 vp, i32, f32, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
@@ -51,6 +51,8 @@ SIGNATURES = {
     "advs_window_shift": [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "advs_cls_mean_rows_f32": [vp, vp, i32, i32, i32, i32, i32, vp],
     "advs_dwconv2d": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    "advs_dwconv2d_act": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "advs_scale_channels": [vp, vp, vp, i32, i32, i32, i32, vp],
     "advs_space_to_depth2": [vp, vp, i32, i32, i32, i32, i32, vp],
     "advs_patchify": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "advs_patchify_padded": [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],

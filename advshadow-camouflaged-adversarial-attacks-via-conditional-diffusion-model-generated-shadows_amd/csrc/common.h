@@ -126,6 +126,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
         case ADVS_ACT_RELU6: return fminf(fmaxf(v, 0.f), 6.f);
         case ADVS_ACT_LRELU01: return v > 0.f ? v : 0.1f * v;
         case ADVS_ACT_LRELU001: return v > 0.f ? v : 0.01f * v;
+        case ADVS_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
         default: return v;
     }
 }

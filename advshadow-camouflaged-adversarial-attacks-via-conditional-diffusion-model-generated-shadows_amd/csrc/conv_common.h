@@ -85,6 +85,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvKP& p, f32x16 (&acc)[TM]
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { bias[e] = (p.bias && n_ok) ? p.bias[n + e] : 0.f; ssum[e] = 0.f; ssq[e] = 0.f; }
     const bool temb_rowwise = p.temb && temb_b < 0;
+    const bool res_after = (p.act & ADVS_GN_RESIDUAL_AFTER_ACT) != 0;       // same flag bit as advs_groupnorm's act
+    const int act = p.act & ~ADVS_GN_RESIDUAL_AFTER_ACT;
     if (p.temb && temb_b >= 0 && n_ok) {
         const float* tp = p.temb + (size_t)temb_b * p.temb_stride + n;
 #pragma unroll
@@ -129,15 +131,19 @@ __device__ __forceinline__ void conv_epilogue(const ConvKP& p, f32x16 (&acc)[TM]
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) v[e] += tp[e];
                 }
-                if (res) {
-                    float rv[VEC];
-                    unpack16<T>(rraw[it], rv);
+                float rv[VEC];
+                if (res) unpack16<T>(rraw[it], rv);
+                if (res && !res_after) {
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) v[e] += rv[e];
                 }
-                if (p.act != ADVS_ACT_NONE) {
+                if (act != ADVS_ACT_NONE) {
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) v[e] = apply_act(v[e], p.act);
+                    for (int e = 0; e < VEC; ++e) v[e] = apply_act(v[e], act);
+                }
+                if (res && res_after) {                  // y = act(conv) + x (FusedMBConv with expand 1: Conv-BN-SiLU, then add)
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) v[e] += rv[e];
                 }
                 const u32x4 packed = pack16<T>(v);
                 *(u32x4*)(y + o) = packed;

@@ -228,7 +228,7 @@ extern "C" int advs_gather_rows_f32(const void* x, float* y, int b, long long ro
 template <typename T>
 __global__ void __launch_bounds__(256)
 dwconv_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, T* __restrict__ y,
-              int B, int H, int W, int C, int K, int stride, int Ho, int Wo) {
+              int B, int H, int W, int C, int K, int stride, int Ho, int Wo, int act) {
     constexpr int VEC = Elt<T>::VEC;
     const int vpp = C / VEC, pad = K / 2;
     const size_t total = (size_t)B * Ho * Wo * vpp;
@@ -254,12 +254,22 @@ dwconv_kernel(const T* __restrict__ x, const float* __restrict__ w, const float*
                 for (int e = 0; e < VEC; ++e) acc[e] = fmaf(f[e], wt[e], acc[e]);
             }
         }
+        if (act != ADVS_ACT_NONE) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[e] = apply_act(acc[e], act);
+        }
         *((u32x4*)(y + (((size_t)b * Ho + oy) * Wo + ox) * C) + cv) = pack16<T>(acc);
     }
 }
 
+extern "C" int advs_dwconv2d_act(const void* x, const float* w_taps_c, const float* bias, void* y, int b, int h, int w, int c,
+                                 int ksize, int stride, int act, int dtype, void* stream);
 extern "C" int advs_dwconv2d(const void* x, const float* w_taps_c, const float* bias, void* y, int b, int h, int w, int c,
                              int ksize, int stride, int dtype, void* stream) {
+    return advs_dwconv2d_act(x, w_taps_c, bias, y, b, h, w, c, ksize, stride, ADVS_ACT_NONE, dtype, stream);
+}
+extern "C" int advs_dwconv2d_act(const void* x, const float* w_taps_c, const float* bias, void* y, int b, int h, int w, int c,
+                                 int ksize, int stride, int act, int dtype, void* stream) {
     ADVS_REQUIRE(dtype_ok(dtype), "advs_dwconv2d: unknown dtype code %d", dtype);
     ADVS_REQUIRE(x && w_taps_c && y && b > 0 && h > 0 && w > 0 && c > 0, "dwconv2d: bad args");
     ADVS_REQUIRE((ksize & 1) && ksize >= 1 && ksize <= 7 && (stride == 1 || stride == 2), "dwconv2d: ksize %d / stride %d unsupported", ksize, stride);
@@ -268,7 +278,7 @@ extern "C" int advs_dwconv2d(const void* x, const float* w_taps_c, const float* 
     const int ho = (h + 2 * (ksize / 2) - ksize) / stride + 1, wo = (w + 2 * (ksize / 2) - ksize) / stride + 1;
     const size_t total = (size_t)b * ho * wo * (c / vec);
     const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    ADVS_SWITCH_T(dtype, dwconv_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T*)x, w_taps_c, bias, (T*)y, b, h, w, c, ksize, stride, ho, wo));
+    ADVS_SWITCH_T(dtype, dwconv_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T*)x, w_taps_c, bias, (T*)y, b, h, w, c, ksize, stride, ho, wo, act));
     ADVS_CHECK_LAUNCH("dwconv2d");
     return ADVS_OK;
 }
@@ -383,5 +393,35 @@ extern "C" int advs_cls_mean_rows_f32(const void* tokens, float* y, int b, int n
     dim3 grid(cdiv(c, 64), b);
     ADVS_SWITCH_T(dtype, cls_mean_rows_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T*)tokens, y, n_pad, np, c));
     ADVS_CHECK_LAUNCH("cls_mean_rows");
+    return ADVS_OK;
+}
+
+
+// squeeze-and-excitation scale (torchvision SqueezeExcitation.forward: scale * input), s is f32 [B][C]
+template <typename T>
+__global__ void scale_channels_kernel(const T* __restrict__ x, const float* __restrict__ s, T* __restrict__ y, int B, int HW, int C) {
+    constexpr int VEC = Elt<T>::VEC;
+    const int vpp = C / VEC;
+    const size_t total = (size_t)B * HW * vpp;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % vpp);
+        const int b = (int)(i / ((size_t)HW * vpp));
+        float f[VEC];
+        unpack16<T>(((const u32x4*)x)[i], f);
+        const float* sp = s + (size_t)b * C + cv * VEC;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) f[e] *= sp[e];
+        ((u32x4*)y)[i] = pack16<T>(f);
+    }
+}
+extern "C" int advs_scale_channels(const void* x, const float* s, void* y, int b, int hw, int c, int dtype, void* stream) {
+    ADVS_REQUIRE(dtype_ok(dtype), "advs_scale_channels: unknown dtype code %d", dtype);
+    ADVS_REQUIRE(x && s && y && b > 0 && hw > 0 && c > 0, "scale_channels: bad args");
+    const int vec = dtype == ADVS_F32 ? 4 : 8;
+    ADVS_REQUIRE(c % vec == 0, "scale_channels: c=%d must be a multiple of %d", c, vec);
+    const size_t total = (size_t)b * hw * (c / vec);
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    ADVS_SWITCH_T(dtype, scale_channels_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T*)x, s, (T*)y, b, hw, c));
+    ADVS_CHECK_LAUNCH("scale_channels");
     return ADVS_OK;
 }

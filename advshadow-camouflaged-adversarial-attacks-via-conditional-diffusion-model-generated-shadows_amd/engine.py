@@ -142,7 +142,8 @@ class Builder:
 
     # ---- ops (activations are NHWC tensors [B,H,W,C] of the compute dtype)
     def conv(self, x1, w, cout, *, x2=None, bias=None, temb=None, temb_stride=0, residual=None,
-             ksize=3, stride=1, pad=1, upsample=False, act=None, out=None, tile=0, want_stats=False, extra=None):
+             ksize=3, stride=1, pad=1, upsample=False, act=None, out=None, tile=0, want_stats=False, extra=None,
+             residual_after_act=False):
         """extra = (e1, e2_or_None): NHWC tensors at the OUTPUT resolution whose 1x1 conv is summed in;
         ``w`` then holds [taps * (C1 + C2) | E1 + E2] per output channel."""
         B, H, W, L1 = x1.shape
@@ -158,7 +159,7 @@ class Builder:
         y = out if out is not None else self.buf((B, Ho, Wo, cout))
         a = ConvArgs(ptr(x1), ptr(x2), ptr(w), ptr(bias), ptr(temb), ptr(residual), ptr(y),
                      B, H, W, C1, C2, cout, ksize, stride, pad, 2 if subpixel else (1 if upsample else 0),
-                     ACT[act], self.dt, temb_stride, tile, 0, 0,
+                     ACT[act] | (GN_RESIDUAL_AFTER_ACT if residual_after_act else 0), self.dt, temb_stride, tile, 0, 0,
                      ptr(extra[0]) if extra else 0, ptr(extra[1]) if extra and extra[1] is not None else 0,
                      extra[0].shape[3] if extra else 0, extra[1].shape[3] if extra and extra[1] is not None else 0,
                      L1 if L1 != C1 else 0, L2 if L2 != C2 else 0)

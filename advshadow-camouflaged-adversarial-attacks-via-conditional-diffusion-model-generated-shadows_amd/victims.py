@@ -994,3 +994,199 @@ class Dinov2Victim(nn.Module):
         return eng
 
     forward = ViTVictim.forward
+
+
+# ============================================================================ EfficientNetV2-S (torchvision names)
+_EFFNETV2_S = [("fused", 1, 3, 1, 24, 24, 2), ("fused", 4, 3, 2, 24, 48, 4), ("fused", 4, 3, 2, 48, 64, 4),
+               ("mb", 4, 3, 2, 64, 128, 6), ("mb", 6, 3, 1, 128, 160, 9), ("mb", 6, 3, 2, 160, 256, 15)]
+
+
+class EfficientNetV2S(nn.Module):
+    """torchvision ``efficientnet_v2_s`` with ``classifier[1] = Linear(1280, 37)`` (ASR_fast.py:59-65) on the HIP
+    kernels: BatchNorm (eps 1e-3) folded into every conv, FusedMBConv = 3x3 GEMM (+1x1 projection), MBConv = 1x1
+    expansion -> depthwise 3x3 (+SiLU) -> squeeze-excitation (pool, two tiny Linears, per-channel scale) -> 1x1
+    projection (+residual in the epilogue).  Parameter names follow torchvision (``features.s.b.block.k.{0,1}``,
+    ``block.2.fc{1,2}``, ``classifier.1``).  torchvision is not installed here: PARITY UNPINNED (the architecture is
+    restated in oracle/victims.py and its parameter count equals the published 21,458,488 for 1000 classes)."""
+
+    def __init__(self, num_classes=37, setting=None, last_channel=1280, image_size=224, compute_dtype="fp32", use_graph=True):
+        super().__init__()
+        self.num_classes, self.setting, self.last = num_classes, [tuple(s) for s in (setting or _EFFNETV2_S)], last_channel
+        self.image_size, self.compute_dtype, self.use_graph = image_size, compute_dtype, use_graph
+        self.layout = [("cna", "features.0", 3, self.setting[0][4], 3, 2)]
+        for si, (kind, e, k, s, cin, cout, n) in enumerate(self.setting, start=1):
+            for b in range(n):
+                ci, st = (cin, s) if b == 0 else (cout, 1)
+                self.layout.append((kind, f"features.{si}.{b}", e, k, st, ci, cout))
+        self.layout.append(("cna", f"features.{len(self.setting) + 1}", self.setting[-1][5], last_channel, 1, 1))
+        for item in self.layout:
+            if item[0] == "cna":
+                self._cna(item[1], item[2], item[3], item[4], item[5])
+                continue
+            kind, p, e, k, st, ci, co = item
+            ce = ci * e
+            if kind == "fused":
+                if e != 1:
+                    self._cna(p + ".block.0", ci, ce, k, st); self._cna(p + ".block.1", ce, co, 1, 1)
+                else:
+                    self._cna(p + ".block.0", ci, co, k, st)
+            else:
+                self._cna(p + ".block.0", ci, ce, 1, 1); self._cna(p + ".block.1", ce, ce, k, st, groups=ce)
+                sq = max(1, ci // 4)
+                _attach(self, p + ".block.2.fc1", nn.Conv2d(ce, sq, 1)); _attach(self, p + ".block.2.fc2", nn.Conv2d(sq, ce, 1))
+                self._cna(p + ".block.3", ce, co, 1, 1)
+        _attach(self, "classifier.1", nn.Linear(last_channel, num_classes))
+        self._packed, self._engines = {}, {}
+
+    def _cna(self, p, cin, cout, k, stride, groups=1):
+        _attach(self, p + ".0", nn.Conv2d(cin, cout, k, stride=stride, padding=(k - 1) // 2, groups=groups, bias=False))
+        _attach(self, p + ".1", nn.BatchNorm2d(cout, eps=1e-3))
+
+    def _version(self):
+        dev = next(self.parameters()).device
+        return (str(dev), sum(p._version for p in self.parameters()) + sum(b._version for b in self.buffers()))
+
+    @staticmethod
+    def _pad8(c):
+        return -(-c // 32) * 32 if c < 32 else c              # the 24-channel stage is carried in 32 channels (zeros)
+
+    def packed_weights(self, dt):
+        ver = self._version()
+        hit = self._packed.get(dt)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise _lib.AdvsError(f"EfficientNetV2S parameters are on {dev}: move the model to the GPU; there is no CPU fallback")
+        sd = {k: v.detach() for k, v in self.state_dict().items()}
+        W = {}
+        pad = self._pad8
+
+        def fold(p):                                           # conv weight * bn scale, bn shift as bias (eps 1e-3)
+            scale = sd[p + ".1.weight"].float() / torch.sqrt(sd[p + ".1.running_var"].float() + 1e-3)
+            return sd[p + ".0.weight"].float() * scale[:, None, None, None], sd[p + ".1.bias"].float() - sd[p + ".1.running_mean"].float() * scale
+
+        def gemm(p, name):                                     # zero-pad narrow channel counts on both sides, then pack
+            w, b = fold(p)
+            co, ci = pad(w.shape[0]), pad(w.shape[1])
+            wp = torch.zeros((co, ci) + tuple(w.shape[2:]), device=dev)
+            wp[:w.shape[0], :w.shape[1]] = w
+            bp = torch.zeros(co, device=dev)
+            bp[:b.numel()] = b
+            W[name + ".w"], W[name + ".b"] = pack_conv_weight(wp, dt), bp.contiguous()
+
+        w0, b0 = fold("features.0")
+        c0 = pad(w0.shape[0])
+        ws = torch.zeros((c0, 3, 3, 3), device=dev); ws[:w0.shape[0]] = w0
+        bs = torch.zeros(c0, device=dev); bs[:b0.numel()] = b0
+        W["stem.w"], W["stem.b"] = ws.contiguous(), bs.contiguous()
+        for item in self.layout[1:]:
+            if item[0] == "cna":
+                gemm(item[1], "head")
+                continue
+            kind, p, e, k, st, ci, co = item
+            if kind == "fused":
+                gemm(p + ".block.0", p + ".c0")
+                if e != 1:
+                    gemm(p + ".block.1", p + ".c1")
+            else:
+                gemm(p + ".block.0", p + ".c0")
+                wd, bd = fold(p + ".block.1")
+                W[p + ".dw.w"] = wd.reshape(wd.shape[0], k * k).t().contiguous()                     # [k*k][C]
+                W[p + ".dw.b"] = bd.contiguous()
+                for n in ("fc1", "fc2"):
+                    W[f"{p}.{n}.w"] = sd[f"{p}.block.2.{n}.weight"].float().reshape(sd[f"{p}.block.2.{n}.weight"].shape[0], -1).contiguous()
+                    W[f"{p}.{n}.b"] = sd[f"{p}.block.2.{n}.bias"].float().contiguous()
+                gemm(p + ".block.3", p + ".c3")
+        W["cls.w"], W["cls.b"] = sd["classifier.1.weight"].float().contiguous(), sd["classifier.1.bias"].float().contiguous()
+        self._packed[dt] = (ver, W)
+        for key in [k for k in self._engines if k[1] == dt]:
+            del self._engines[key]
+        return W
+
+    def engine(self, batch, dtype=None):
+        dt = dtype_code(dtype if dtype is not None else self.compute_dtype)
+        W = self.packed_weights(dt)
+        eng = self._engines.get((batch, dt))
+        if eng is None:
+            eng = _EffNetEngine(self, W, batch, dt)
+            self._engines[(batch, dt)] = eng
+        return eng
+
+    def forward(self, x):
+        if x.shape[2] != self.image_size or x.shape[3] != self.image_size:
+            raise ValueError(f"EfficientNetV2S was built for {self.image_size}x{self.image_size} inputs, got {tuple(x.shape[2:])}")
+        eng = self.engine(x.shape[0])
+        cur = torch.cuda.current_stream(x.device)
+        eng.stream.wait_stream(cur)
+        with torch.cuda.stream(eng.stream):
+            eng.x.copy_(x.to(torch.float32), non_blocking=True)
+            eng.run()
+            out = eng.logits.clone()
+        cur.wait_stream(eng.stream)
+        out.record_stream(cur)
+        return out
+
+
+class _EffNetEngine:
+    def __init__(self, model, W, batch, dt):
+        dev = next(model.parameters()).device
+        self.model, self.stream = model, torch.cuda.Stream(device=dev)
+        S, pad = model.image_size, model._pad8
+        with torch.cuda.device(dev):
+            bld = Builder(dev, dt, self.stream, batch)
+            lib = bld.lib
+            self.x = torch.zeros((batch, 3, S, S), dtype=torch.float32, device=dev)
+            c0 = W["stem.b"].numel()
+            side = (S + 2 - 3) // 2 + 1
+            h = bld.buf((batch, side, side, c0))
+            bld.plan.add(lib.advs_conv_stem, ptr(self.x), ptr(W["stem.w"]), ptr(W["stem.b"]), ptr(h), batch, 3, S, S, c0, 3, 2, 1,
+                         _lib.ACT["silu"], dt, keep=(self.x, h))
+            for item in model.layout[1:]:
+                if item[0] == "cna":
+                    new = bld.conv(h, W["head.w"], model.last, bias=W["head.b"], act="silu", ksize=1, pad=0)
+                    bld.free(h)
+                    h = new
+                    continue
+                kind, p, e, k, st, ci, co = item
+                res = h if (st == 1 and ci == co) else None
+                cop, cep = pad(co), pad(ci * e)
+                if kind == "fused" and e == 1:
+                    new = bld.conv(h, W[p + ".c0.w"], cop, bias=W[p + ".c0.b"], act="silu", stride=st, residual=res,
+                                   residual_after_act=res is not None)
+                elif kind == "fused":
+                    m = bld.conv(h, W[p + ".c0.w"], cep, bias=W[p + ".c0.b"], act="silu", stride=st)
+                    new = bld.conv(m, W[p + ".c1.w"], cop, bias=W[p + ".c1.b"], residual=res, ksize=1, pad=0)
+                    bld.free(m)
+                else:
+                    m = bld.conv(h, W[p + ".c0.w"], cep, bias=W[p + ".c0.b"], act="silu", ksize=1, pad=0)
+                    so = (m.shape[1] + 2 - 3) // st + 1
+                    d = bld.buf((batch, so, so, cep))
+                    bld.plan.add(lib.advs_dwconv2d_act, ptr(m), ptr(W[p + ".dw.w"]), ptr(W[p + ".dw.b"]), ptr(d), batch, m.shape[1],
+                                 m.shape[2], cep, k, st, _lib.ACT["silu"], dt, keep=(m, d))
+                    bld.free(m)
+                    pooled = bld.buf((batch, cep), torch.float32)
+                    bld.plan.add(lib.advs_global_avgpool, ptr(d), ptr(pooled), batch, so * so, cep, dt, keep=(d, pooled))
+                    s1 = bld.linear(pooled, W[p + ".fc1.w"], W[p + ".fc1.b"], act_out="silu")
+                    s2 = bld.linear(s1, W[p + ".fc2.w"], W[p + ".fc2.b"], act_out="sigmoid")
+                    sc = bld.buf((batch, so, so, cep))
+                    bld.plan.add(lib.advs_scale_channels, ptr(d), ptr(s2), ptr(sc), batch, so * so, cep, dt, keep=(d, s2, sc))
+                    bld.free(d)
+                    new = bld.conv(sc, W[p + ".c3.w"], cop, bias=W[p + ".c3.b"], residual=res, ksize=1, pad=0)
+                    bld.free(sc)
+                bld.free(h)
+                h = new
+            pooled = bld.buf((batch, model.last), torch.float32)
+            bld.plan.add(lib.advs_global_avgpool, ptr(h), ptr(pooled), batch, h.shape[1] * h.shape[2], model.last, dt, keep=(h, pooled))
+            bld.free(h)
+            self.logits = bld.linear(pooled, W["cls.w"], W["cls.b"])
+            self.plan, self.captured = bld.plan, False
+            torch.cuda.synchronize(dev)
+
+    def run(self):
+        if self.model.use_graph and not self.captured:
+            self.plan.run_eager()
+            self.stream.synchronize()
+            self.plan.capture()
+            self.captured = True
+        self.plan.run()

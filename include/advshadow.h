@@ -25,7 +25,7 @@ extern "C" {
 enum { ADVS_OK = 0, ADVS_ERR_ARG = -1, ADVS_ERR_HIP = -2, ADVS_ERR_STATE = -3 };
 enum { ADVS_F32 = 0, ADVS_BF16 = 1, ADVS_F16 = 2 };   /* 16-bit modes: 16-bit storage + MFMA, f32 accumulation */
 enum { ADVS_ACT_NONE = 0, ADVS_ACT_RELU = 1, ADVS_ACT_SILU = 2, ADVS_ACT_GELU = 3,
-       ADVS_ACT_RELU6 = 4, ADVS_ACT_LRELU01 = 5, ADVS_ACT_LRELU001 = 6 };
+       ADVS_ACT_RELU6 = 4, ADVS_ACT_LRELU01 = 5, ADVS_ACT_LRELU001 = 6, ADVS_ACT_SIGMOID = 7 };
 /* OR-ed into advs_groupnorm*'s `act`: y = act(norm(x)) + chan_add + residual instead of
  * act(norm(x) + residual) + chan_add -- Bottleneck's `y = conv2(conv1(x)); y = y + x`
  * (model/modules/module.py:42-47) where conv2 is Conv -> GroupNorm -> act (conv.py:96-97).   */
@@ -70,7 +70,7 @@ typedef struct advs_conv_args {
                                            parity (a,b) = 2a+b, with the coinciding taps of the 3x3 kernel summed:
                                            rows {w0, w1+w2} for a = 0, {w0+w1, w2} for a = 1, columns likewise.
                                            3x3 stride 1 pad 1, h and w multiples of 16.                          */
-    int act, dtype;
+    int act, dtype;                     /* act may carry ADVS_GN_RESIDUAL_AFTER_ACT: y = act(conv + bias) + residual */
     int temb_stride;                    /* floats between consecutive samples' temb rows    */
     int tile;                           /* 0 = choose; 1: 128x128, 2|3: 256x128, 4: 256x256,
                                            10: 16x16-pixel halo tile (3x3 stride 1 only); 12 (implied by
@@ -283,6 +283,11 @@ int advs_cls_mean_rows_f32(const void* tokens, float* y, int b, int n_pad, int n
  * [k*k][c] f32.  y is [b][ho][wo][c].                                                                          */
 int advs_dwconv2d(const void* x, const float* w_taps_c, const float* bias, void* y, int b, int h, int w, int c,
                   int ksize, int stride, int dtype, void* stream);
+/* ... followed by an activation (EfficientNetV2's depthwise Conv-BN-SiLU, BN folded by the host).                 */
+int advs_dwconv2d_act(const void* x, const float* w_taps_c, const float* bias, void* y, int b, int h, int w, int c,
+                      int ksize, int stride, int act, int dtype, void* stream);
+/* Squeeze-and-excitation scale: y[b][p][c] = x[b][p][c] * s[b][c], s f32 [b][c] (torchvision SqueezeExcitation).    */
+int advs_scale_channels(const void* x, const float* s, void* y, int b, int hw, int c, int dtype, void* stream);
 /* [b][h][w][c] -> [b][h/2][w/2][4c], channel (dy*2+dx)*c + ch: a Conv2d(c, cout, 2, stride 2) becomes a 1x1 conv. */
 int advs_space_to_depth2(const void* x, void* y, int b, int h, int w, int c, int dtype, void* stream);
 

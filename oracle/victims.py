@@ -132,3 +132,95 @@ def hf_dinov2(num_labels=37, seed=9, **cfg):
             elif n.endswith("bias"):
                 p.copy_(torch.randn_like(p) * 0.05)
     return m
+
+
+# --------------------------------------------------------------------------- EfficientNetV2-S (torchvision)
+# torchvision.models.efficientnet_v2_s as published (torchvision/models/efficientnet.py): (block, expand, kernel,
+# stride, in, out, layers); BatchNorm eps 1e-3; SE squeeze = max(1, in // 4) with SiLU / Sigmoid; stem 3->24 s2;
+# head 256->1280; classifier[1] = Linear(1280, classes) (ASR_fast.py:59-65).  torchvision is absent from this image:
+# PARITY UNPINNED (architecture and parameter names restated from the published source, not checked against it).
+EFFNETV2_S = [("fused", 1, 3, 1, 24, 24, 2), ("fused", 4, 3, 2, 24, 48, 4), ("fused", 4, 3, 2, 48, 64, 4),
+              ("mb", 4, 3, 2, 64, 128, 6), ("mb", 6, 3, 1, 128, 160, 9), ("mb", 6, 3, 2, 160, 256, 15)]
+
+
+def effnetv2_layout(setting=EFFNETV2_S, last=1280):
+    """[(kind, prefix, args...)] in torchvision's module order with its state_dict prefixes."""
+    out = [("cna", "features.0", 3, setting[0][4], 3, 2, True)]
+    for si, (kind, e, k, s, cin, cout, n) in enumerate(setting, start=1):
+        for b in range(n):
+            ci, st = (cin, s) if b == 0 else (cout, 1)
+            out.append((kind, f"features.{si}.{b}", e, k, st, ci, cout))
+    out.append(("cna", f"features.{len(setting) + 1}", setting[-1][5], last, 1, 1, True))
+    return out
+
+
+def effnetv2_init(seed, num_classes=37, setting=EFFNETV2_S, last=1280):
+    """Random parameters with torchvision's names (BatchNorm statistics randomised so that folding is exercised)."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+
+    def cna(p, cin, cout, k, groups=1):
+        fan = cin // groups * k * k
+        sd[p + ".0.weight"] = torch.randn(cout, cin // groups, k, k, generator=g) * (1.6 / fan) ** 0.5
+        sd[p + ".1.weight"] = torch.rand(cout, generator=g) * 0.5 + 0.75
+        sd[p + ".1.bias"] = torch.randn(cout, generator=g) * 0.1
+        sd[p + ".1.running_mean"] = torch.randn(cout, generator=g) * 0.1
+        sd[p + ".1.running_var"] = torch.rand(cout, generator=g) * 0.5 + 0.75
+        sd[p + ".1.num_batches_tracked"] = torch.tensor(0)
+
+    for item in effnetv2_layout(setting, last):
+        if item[0] == "cna":
+            cna(item[1], item[2], item[3], item[4])
+            continue
+        kind, p, e, k, st, ci, co = item
+        ce = ci * e
+        if kind == "fused":
+            if e != 1:
+                cna(p + ".block.0", ci, ce, k); cna(p + ".block.1", ce, co, 1)
+            else:
+                cna(p + ".block.0", ci, co, k)
+        else:
+            cna(p + ".block.0", ci, ce, 1); cna(p + ".block.1", ce, ce, k, groups=ce)
+            sq = max(1, ci // 4)
+            sd[p + ".block.2.fc1.weight"] = torch.randn(sq, ce, 1, 1, generator=g) * (1.0 / ce) ** 0.5
+            sd[p + ".block.2.fc1.bias"] = torch.randn(sq, generator=g) * 0.1
+            sd[p + ".block.2.fc2.weight"] = torch.randn(ce, sq, 1, 1, generator=g) * (1.0 / sq) ** 0.5
+            sd[p + ".block.2.fc2.bias"] = torch.randn(ce, generator=g) * 0.1 + 1.0
+            cna(p + ".block.3", ce, co, 1)
+    sd["classifier.1.weight"] = torch.randn(num_classes, last, generator=g) * (1.0 / last) ** 0.5
+    sd["classifier.1.bias"] = torch.randn(num_classes, generator=g) * 0.1
+    return sd
+
+
+@torch.no_grad()
+def effnetv2_forward(sd, x, setting=EFFNETV2_S, last=1280):
+    """EfficientNet.forward (eval mode: BatchNorm running statistics, StochasticDepth = identity)."""
+    def cna(p, h, stride=1, groups=1, act=True):
+        w = sd[p + ".0.weight"]
+        h = F.conv2d(h, w, stride=stride, padding=(w.shape[-1] - 1) // 2, groups=groups)
+        h = F.batch_norm(h, sd[p + ".1.running_mean"], sd[p + ".1.running_var"], sd[p + ".1.weight"], sd[p + ".1.bias"], False, 0.0, 1e-3)
+        return F.silu(h) if act else h
+
+    h = x
+    for item in effnetv2_layout(setting, last):
+        if item[0] == "cna":
+            h = cna(item[1], h, stride=item[5])
+            continue
+        kind, p, e, k, st, ci, co = item
+        inp = h
+        if kind == "fused":
+            if e != 1:
+                h = cna(p + ".block.1", cna(p + ".block.0", h, stride=st), act=False)
+            else:
+                h = cna(p + ".block.0", h, stride=st)
+        else:
+            h = cna(p + ".block.0", h)
+            h = cna(p + ".block.1", h, stride=st, groups=h.shape[1])
+            s = F.adaptive_avg_pool2d(h, 1)
+            s = F.silu(F.conv2d(s, sd[p + ".block.2.fc1.weight"], sd[p + ".block.2.fc1.bias"]))
+            s = torch.sigmoid(F.conv2d(s, sd[p + ".block.2.fc2.weight"], sd[p + ".block.2.fc2.bias"]))
+            h = cna(p + ".block.3", h * s, act=False)
+        if st == 1 and ci == co:
+            h = h + inp
+    h = F.adaptive_avg_pool2d(h, 1).flatten(1)
+    return F.linear(h, sd["classifier.1.weight"], sd["classifier.1.bias"])

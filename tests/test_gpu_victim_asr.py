@@ -281,3 +281,27 @@ def test_dinov2_matches_hf_transformers():
             assert (got - ref).abs().max().item() < bound * scale, (size, dt, (got - ref).abs().max().item())
             if dt == "fp32":
                 assert torch.equal(got.argmax(1), ref.argmax(1))
+
+
+# ------------------------------------------------------------------------------ EfficientNetV2-S (ASR_fast.py:59-65)
+def test_efficientnet_v2_s_vs_restatement():
+    """PARITY UNPINNED (torchvision absent): the product against oracle/victims.py's restatement of the published
+    architecture, whose parameter count is checked against torchvision's published 21,458,488 (1000 classes)."""
+    from advshadow_amd.victims import EfficientNetV2S
+    sd1000 = ov.effnetv2_init(0, 1000)
+    assert sum(v.numel() for k, v in sd1000.items() if "running" not in k and "num_batches" not in k) == 21458488
+    sd = ov.effnetv2_init(3, 37)
+    net = EfficientNetV2S(37, image_size=64)
+    assert sorted(net.state_dict().keys()) == sorted(sd.keys())
+    net.load_state_dict(sd)
+    x = torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(16))
+    ref = ov.effnetv2_forward(sd, x)
+    scale = max(1.0, ref.abs().max().item())
+    got = net.to("cuda").eval()(x.cuda()).cpu()
+    assert (got - ref).abs().max().item() < 5e-4 * scale, (got - ref).abs().max().item()
+    assert torch.equal(got.argmax(1), ref.argmax(1))
+    for dt, bound in (("fp16", 0.03), ("bf16", 0.15)):
+        lp = EfficientNetV2S(37, image_size=64, compute_dtype=dt)
+        lp.load_state_dict(sd)
+        got = lp.to("cuda").eval()(x.cuda()).cpu()
+        assert (got - ref).abs().max().item() < bound * scale, (dt, (got - ref).abs().max().item())
