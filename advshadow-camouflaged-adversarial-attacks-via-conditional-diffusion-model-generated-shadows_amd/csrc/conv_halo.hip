@@ -52,9 +52,13 @@ template <int NT> __host__ __device__ constexpr int halo_a_pieces(int t) {
     return NT == 9 ? ((t >= 0 && t < HNP) ? 1 : 0) : ((t == 0 || t == 1) ? 3 : 0);
 }
 
-template <typename T, int NT>
+// XT: the fused 1x1 operand of ResidualBlock.shortcut (conv_igemm.hip) follows the 3x3 slabs as extra "units" of ONE tap
+// each -- the centre tap of the same halo staging, reading e1 / e2 and the weight columns behind the 9*Cin block.  A
+// one-tap unit cannot hide its own staging (8 LDS-DMA pieces per 16 MFMAs), but the 3x3 part keeps the halo kernel's rate.
+template <typename T, int NT, bool XT = false>
 __global__ void __launch_bounds__(512)
 conv3x3_halo_kernel(const ConvKP p) {
+    static_assert(!XT || NT == 9, "the extra operand is only wired into the 3x3 kernel");
     constexpr int ESZ = Mma<T>::ESZ;
     constexpr int NTW = NT == 9 ? 3 : 2;                         // taps per filter row
     constexpr int BKE = SLAB / ESZ;
@@ -107,23 +111,43 @@ conv3x3_halo_kernel(const ConvKP p) {
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x1, 0, p.x1_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x2 ? p.x2 : p.x1), 0, p.x2_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rse1 = __builtin_amdgcn_make_buffer_rsrc((void*)(XT ? p.e1 : p.x1), 0, XT ? p.e1_bytes : 16, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rse2 = __builtin_amdgcn_make_buffer_rsrc((void*)(XT && p.e2 ? p.e2 : p.x1), 0, XT ? p.e2_bytes : 16, 0x00020000);
 
     const int Cin = p.C1 + p.C2;
     const int ncs1 = p.C1 / BKE, nunits = Cin / BKE;   // one unit = one 128-byte channel slab (all 9 taps)
+    const int ne1 = XT ? p.E1 / BKE : 0, ne = XT ? (p.E1 + p.E2) / BKE : 0;      // one-tap units of the extra operand
+    const int gtaps = nunits * NT + ne;                // taps in all
 
     auto set_a_voff = [&](int unit) {                // byte offsets of the halo pixels in `unit`'s source
-        const unsigned cs = (unsigned)(unit < ncs1 ? p.LD1 : p.LD2) * ESZ;
+        unsigned cs = (unsigned)(unit < ncs1 ? p.LD1 : p.LD2) * ESZ;
+        if (XT && unit >= nunits) cs = (unsigned)(unit - nunits < ne1 ? p.E1 : p.E2) * ESZ;
 #pragma unroll
         for (int j = 0; j < HNP; ++j) a_voff[j] = apix[j] >= 0 ? (unsigned)apix[j] * cs + acsw[j] : OOB_OFFSET;
     };
     auto issue_A = [&](int unit, int j) {
         char* dst = sA + (unit & 1) * HA_STAGE + a_dst[j];
-        if (unit < ncs1) blds16(rs1, a_voff[j], (unsigned)unit * SLAB, dst);
+        if (XT && unit >= nunits) {
+            const int e = unit - nunits;
+            if (e < ne1) blds16(rse1, a_voff[j], (unsigned)e * SLAB, dst);
+            else blds16(rse2, a_voff[j], (unsigned)(e - ne1) * SLAB, dst);
+        } else if (unit < ncs1) blds16(rs1, a_voff[j], (unsigned)unit * SLAB, dst);
         else blds16(rs2, a_voff[j], (unsigned)(unit - ncs1) * SLAB, dst);
     };
     auto issue_B = [&](int unit, int t, int j) {     // weights of (slab unit, tap t): K offset t*Cin + unit*BKE
         const unsigned woff = (unsigned)(t * Cin + unit * BKE) * ESZ;
         blds16(rsw, b_voff[j], woff, sB + ((unit * NT + t) & 3) * HB_STAGE + (wave * 2 + j) * 1024);
+    };
+    auto issue_Bx = [&](int e, int j) {              // weights of extra unit e: K offset NT*Cin + e*BKE, ring slot of its tap
+        const unsigned woff = (unsigned)(NT * Cin + e * BKE) * ESZ;
+        blds16(rsw, b_voff[j], woff, sB + ((nunits * NT + e) & 3) * HB_STAGE + (wave * 2 + j) * 1024);
+    };
+    // weights of the tap three ahead of global tap `it` (none past the end)
+    auto issue_W3 = [&](int unit, int t, int j) {
+        const int g3 = unit * NT + t + 3;
+        if (g3 >= gtaps) return;
+        if (XT && g3 >= nunits * NT) { issue_Bx(g3 - nunits * NT, j); return; }
+        if (t + 3 < NT) issue_B(unit, t + 3, j); else issue_B(unit + 1, t + 3 - NT, j);
     };
 
     // ---- fragment geometry: wave (wr, wc) owns tile rows 4wr..4wr+3 (x16 px) and channels wc*64..+63
@@ -165,8 +189,8 @@ conv3x3_halo_kernel(const ConvKP p) {
     };
 
     for (int unit = 0; unit < nunits; ++unit) {
-        const bool hn = unit + 1 < nunits;           // a next slab exists: its halo is prefetched during this one
-        if (hn && (unit + 1 == ncs1 || unit == 0)) set_a_voff(unit + 1);
+        const bool hn = unit + 1 < nunits + ne;      // a next slab exists: its halo is prefetched during this one
+        if (hn && (unit + 1 == ncs1 || unit == 0 || unit + 1 == nunits || unit + 1 == nunits + ne1)) set_a_voff(unit + 1);
         const char* la = sA + (unit & 1) * HA_STAGE;
         auto tap = [&](auto tc) {
             constexpr int t = decltype(tc)::value;
@@ -174,14 +198,11 @@ conv3x3_halo_kernel(const ConvKP p) {
             // Outstanding, oldest first: W(t+1) [+halo pieces of tap t-2], W(t+2) [+halo pieces of tap t-1].  Wait for
             // W(t+1).  The last tap of a slab reads the NEXT slab's halo at its end: everything but W(t+2) must be in.
             constexpr int nA = t == NT - 1 ? 0 : halo_a_pieces<NT>(t - 2) + halo_a_pieces<NT>(t - 1);
-            if (hn) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + nA) : "memory");
-            else if (t + 2 < NT) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (it + 2 >= gtaps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // no W(t+2): nothing may be pending
+            else if (hn) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + nA) : "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            // W(it+3) wraps into the next slab for the last three taps
-            const bool wb = t + 3 < NT || hn;
-            const int u3 = t + 3 < NT ? unit : unit + 1, t3 = t + 3 < NT ? t + 3 : t + 3 - NT;
             const int r = r0 + t / NTW, s = s0 + t % NTW;
             const char* lb = sB + (it & 3) * HB_STAGE;
             if (it == 0) load_frags(0, la, lb, r, s, 0);              // nothing was carried into the very first tap
@@ -192,12 +213,13 @@ conv3x3_halo_kernel(const ConvKP p) {
                     load_frags(nxt, la, lb, r, s, ks + 1);
                 } else if (t < NT - 1) {                              // first fragments of the next tap, same slab
                     load_frags(nxt, la, sB + ((it + 1) & 3) * HB_STAGE, r0 + (t + 1) / NTW, s0 + (t + 1) % NTW, 0);
-                } else if (hn) {                                      // ... or tap 0 of the next slab's halo
-                    load_frags(nxt, sA + ((unit + 1) & 1) * HA_STAGE, sB + ((it + 1) & 3) * HB_STAGE, r0, s0, 0);
+                } else if (hn) {                                      // ... or the first tap of the next slab's halo
+                    const int nc = (XT && unit + 1 >= nunits) ? 1 : 0;            // an extra unit's only tap is the centre one
+                    load_frags(nxt, sA + ((unit + 1) & 1) * HA_STAGE, sB + ((it + 1) & 3) * HB_STAGE, r0 + nc, s0 + nc, 0);
                 }
                 // this tap's share of the DMA issue, spread between the MFMA groups (weights first)
-                if (ks == 0 && wb) issue_B(u3, t3, 0);
-                if (ks == 1 && wb) issue_B(u3, t3, 1);
+                if (ks == 0) issue_W3(unit, t, 0);
+                if (ks == 1) issue_W3(unit, t, 1);
                 if (NT == 9) {
                     if (ks == 2 && hn && t < HNP) issue_A(unit + 1, t);
                 } else if (hn && t < 2) {                             // three halo pieces in each of taps 0 and 1
@@ -218,6 +240,37 @@ conv3x3_halo_kernel(const ConvKP p) {
             tap(std::integral_constant<int, 7>{}); tap(std::integral_constant<int, 8>{});
         }
     }
+    if constexpr (XT) {
+        for (int e = 0; e < ne; ++e) {
+            const int unit = nunits + e, it = nunits * NT + e;
+            const bool hn = e + 1 < ne;
+            if (hn && e + 1 == ne1) set_a_voff(unit + 1);
+            // this unit's halo was issued during the previous tap, behind W(it+2): everything has to be in
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const char* la = sA + (unit & 1) * HA_STAGE;
+            const char* lb = sB + (it & 3) * HB_STAGE;
+            if (e > 0) load_frags(0, la, lb, 1, 1, 0);               // unit 0's first fragments came with the last 3x3 tap
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int cur = ks & 1, nxt = cur ^ 1;
+                if (ks < 3) load_frags(nxt, la, lb, 1, 1, ks + 1);
+                if (ks < 2 && it + 3 < gtaps) issue_Bx(e + 3, ks);
+                if (hn) {                                            // the next unit's whole halo rides in this one tap
+                    if (ks == 1) { issue_A(unit + 1, 0); issue_A(unit + 1, 1); }
+                    if (ks == 2) { issue_A(unit + 1, 2); issue_A(unit + 1, 3); }
+                    if (ks == 3) { issue_A(unit + 1, 4); issue_A(unit + 1, 5); }
+                }
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) Mma<T>::run(af[cur][i], bf[cur][j], acc[i][j]);
+                __builtin_amdgcn_s_setprio(0);
+            }
+        }
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                    // every wave is done reading before the patches reuse LDS
 
@@ -236,6 +289,11 @@ conv3x3_halo_kernel(const ConvKP p) {
 // multiple of 16 pixels both ways.
 bool conv_halo_eligible(const ConvKP& p) {
     return p.R == 3 && p.stride == 1 && p.pad == 1 && p.ups == 0 && p.e1 == nullptr &&
+           p.H % HT == 0 && p.W % HT == 0 && p.Ho == p.H && p.Wo == p.W;
+}
+// ... with the fused 1x1 operand (stride 1: e1 / e2 live on the same pixel grid)?
+bool conv_halo_extra_eligible(const ConvKP& p) {
+    return p.R == 3 && p.stride == 1 && p.pad == 1 && p.ups == 0 && p.e1 != nullptr &&
            p.H % HT == 0 && p.W % HT == 0 && p.Ho == p.H && p.Wo == p.W;
 }
 // ... and the sub-pixel form of upsample + 3x3 (weights packed per output parity)?
@@ -277,6 +335,27 @@ static int halo_subpixel_launch(ConvKP& p, hipStream_t st) {
 int conv_halo_subpixel_dispatch(ConvKP& p, int dtype, hipStream_t st) {
     ADVS_REQUIRE(conv_halo_subpixel_eligible(p), "conv2d: the sub-pixel upsample conv needs 3x3 stride 1 pad 1, upsample, no extra operand, H and W multiples of 16");
     ADVS_SWITCH_T(dtype, return halo_subpixel_launch<T>(p, st));
+    return ADVS_ERR_ARG;                    // not reached
+}
+
+template <typename T>
+static int halo_extra_launch(ConvKP& p, hipStream_t st) {
+    constexpr int lds = 2 * HA_STAGE + 4 * HB_STAGE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        ADVS_HIP(hipFuncSetAttribute((const void*)conv3x3_halo_kernel<T, 9, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    p.nMt = p.B * (p.H / HT) * (p.W / HT);
+    p.nNt = cdiv(p.Cout, 128);
+    conv3x3_halo_kernel<T, 9, true><<<p.nMt * p.nNt, 512, lds, st>>>(p);
+    ADVS_CHECK_LAUNCH("conv3x3_halo_extra");
+    return ADVS_OK;
+}
+
+int conv_halo_extra_dispatch(ConvKP& p, int dtype, hipStream_t st) {
+    ADVS_REQUIRE(conv_halo_extra_eligible(p), "conv2d: the halo kernel with the fused 1x1 operand needs 3x3 stride 1 pad 1, no upsample, H and W multiples of 16");
+    ADVS_SWITCH_T(dtype, return halo_extra_launch<T>(p, st));
     return ADVS_ERR_ARG;                    // not reached
 }
 

@@ -28,6 +28,7 @@
 //
 // Roofline: MFMA-bound.  Algorithmic FLOPs per launch = 2*M*N*K.
 #include "conv_common.h"
+#include <stdlib.h>
 
 template <typename T, int BM, int BN, int WM, int WN, int NSTAGE, bool ILV>
 __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
@@ -313,6 +314,8 @@ static int pick_tile(long long m_img, int cout);
 bool conv_halo_eligible(const ConvKP& p);
 int conv_halo_dispatch(ConvKP& p, int dtype, hipStream_t st);
 int conv_halo_subpixel_dispatch(ConvKP& p, int dtype, hipStream_t st);
+bool conv_halo_extra_eligible(const ConvKP& p);
+int conv_halo_extra_dispatch(ConvKP& p, int dtype, hipStream_t st);
 
 template <typename T>
 static int conv_dispatch(ConvKP& p, int tile, hipStream_t st) {
@@ -352,7 +355,9 @@ static int resolve_tile(const advs_conv_args* a, long long m_img) {
     if (a->upsample == ADVS_UPSAMPLE_SUBPIXEL) return 12;       // weights are packed per output parity: one kernel only
     if (g_tile_override) return g_tile_override;
     if (a->tile) return a->tile;
-    if (a->ksize == 3 && a->stride == 1 && a->pad == 1 && !a->upsample && !a->e1 && a->h % 16 == 0 && a->w_ % 16 == 0)
+    // (with a fused 1x1 operand tile 10 becomes 13: the same kernel with one-tap units behind the 3x3 slabs, +3 %)
+    static const bool no_halo_extra = getenv("ADVS_NO_HALO_EXTRA") != nullptr;      // A/B knob for tools/
+    if (a->ksize == 3 && a->stride == 1 && a->pad == 1 && !a->upsample && (!a->e1 || !no_halo_extra) && a->h % 16 == 0 && a->w_ % 16 == 0)
         return 10;
     return pick_tile(m_img, a->cout);
 }
@@ -365,7 +370,7 @@ extern "C" int advs_conv_resolve_tile(const advs_conv_args* a) {
     return resolve_tile(a, ho * wo);
 }
 extern "C" int advs_conv_tile_rows(int tile) {
-    switch (tile) { case 1: case 2: case 5: case 6: case 8: case 10: case 12: return 64; case 3: case 4: case 7: case 9: return 128; default: return 0; }
+    switch (tile) { case 1: case 2: case 5: case 6: case 8: case 10: case 12: case 13: return 64; case 3: case 4: case 7: case 9: return 128; default: return 0; }
 }
 
 extern "C" int advs_conv2d(const advs_conv_args* a, void* stream) {
@@ -419,6 +424,7 @@ extern "C" int advs_conv2d(const advs_conv_args* a, void* stream) {
     p.act = a->act; p.temb_stride = a->temb_stride > 0 ? a->temb_stride : a->cout;
     p.dHoWo.init((unsigned)(p.Ho * p.Wo)); p.dWo.init((unsigned)p.Wo);
     int tile = resolve_tile(a, (long long)p.Ho * p.Wo);
+    if (tile == 10 && conv_halo_extra_eligible(p)) tile = 13;   // 13: the halo kernel with the fused 1x1 operand
     if (tile == 10 && !conv_halo_eligible(p)) {
         ADVS_REQUIRE(g_tile_override != 0, "conv2d: tile 10 (halo kernel) needs 3x3 stride 1 pad 1, no upsample / extra operand, H and W multiples of 16");
         tile = pick_tile((long long)p.Ho * p.Wo, a->cout);   // tuning override on a shape the halo kernel cannot take
@@ -431,6 +437,7 @@ extern "C" int advs_conv2d(const advs_conv_args* a, void* stream) {
         else ADVS_REQUIRE(a->stats_rows == wm, "conv2d: stats buffer sized for %d-row blocks but the tile uses %d", a->stats_rows, wm);
     }
     if (tile == 12) return conv_halo_subpixel_dispatch(p, a->dtype, (hipStream_t)stream);
+    if (tile == 13) return conv_halo_extra_dispatch(p, a->dtype, (hipStream_t)stream);
     if (tile == 10) return conv_halo_dispatch(p, a->dtype, (hipStream_t)stream);
     ADVS_SWITCH_T(a->dtype, return conv_dispatch<T>(p, tile, (hipStream_t)stream));
     return ADVS_ERR_ARG;                    // not reached

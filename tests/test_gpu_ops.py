@@ -440,6 +440,45 @@ def test_conv2d_with_extra_1x1_operand(dt, tile, two):
     assert err < tol(dt, 3e-5, 5e-2), err
 
 
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("case", [
+    # B, H, W, Ca (one or two sources), Cout, E1, E2, residual-free full epilogue with temb + stats
+    (2, 16, 16, (128, 0), 128, 64, 0), (1, 32, 16, (128, 0), 128, 256, 128), (2, 16, 16, (64, 64), 256, 128, 128),
+    (1, 16, 48, (64, 0), 64, 64, 64), (3, 16, 16, (128, 0), 128, 192, 0),
+])
+def test_conv2d_extra_operand_on_the_halo_kernel(case, dt):
+    """The fused shortcut operand as one-tap units behind the 3x3 slabs of the halo kernel (tile 10 -> 13): one to six
+    extra slabs, e1 only and e1 + e2, two 3x3 sources, temb and epilogue statistics."""
+    B, H, W, (C1, C2), Cout, E1, E2 = case
+    x1 = rnd(B, C1, H, W, seed=111)
+    x2 = rnd(B, C2, H, W, seed=112) if C2 else None
+    e1 = rnd(B, E1, H, W, seed=113)
+    e2 = rnd(B, E2, H, W, seed=114) if E2 else None
+    w3 = rnd(Cout, C1 + C2, 3, 3, seed=115, scale=1 / math.sqrt(9 * (C1 + C2)))
+    w1 = rnd(Cout, E1 + E2, 1, 1, seed=116, scale=1 / math.sqrt(E1 + E2))
+    bias, temb = rnd(Cout, seed=117), rnd(B, Cout, seed=118)
+    r = lambda t: lp_round(dt, t)
+    xin = x1 if x2 is None else torch.cat([x1, x2], 1)
+    e = e1 if e2 is None else torch.cat([e1, e2], 1)
+    ref = F.conv2d(r(xin), r(w3), bias, padding=1) + F.conv2d(r(e), r(w1)) + temb[:, :, None, None]
+    code = dtype_code(dt)
+    wcat = torch.cat([pack_conv_weight(w3.to(dev()), code).reshape(Cout, -1),
+                      pack_conv_weight(w1.to(dev()), code).reshape(Cout, -1)], 1).contiguous()
+    op = OneOp(dt, B)
+    y = op.b.conv(nhwc(x1, dt), wcat, Cout, x2=nhwc(x2, dt) if C2 else None, bias=bias.to(dev()), temb=temb.to(dev()),
+                  temb_stride=Cout, extra=(nhwc(e1, dt), nhwc(e2, dt) if E2 else None), tile=10, want_stats=True)
+    assert y.data_ptr() in op.b.stats
+    g, be = rnd(Cout, seed=119) + 1, rnd(Cout, seed=120)
+    n = op.b.groupnorm(y, g.to(dev()), be.to(dev()), 32, act="silu")
+    op.go()
+    got = nchw(y)
+    err = (got - ref).abs().max().item()
+    assert err < tol(dt, 3e-5, 5e-2), err
+    refn = F.silu(F.group_norm(got, 32, g, be, eps=1e-5))
+    rel = ((nchw(n) - refn).abs() / refn.abs().clamp(min=1.0)).max().item()
+    assert rel < tol(dt, 2e-5, 1e-2), rel
+
+
 # ------------------------------------------------------------------------------ CSPDarkUnet additions
 @pytest.mark.parametrize("tile", [0, 1, 4, 10])
 @pytest.mark.parametrize("case", [
