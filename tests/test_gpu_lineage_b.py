@@ -166,3 +166,28 @@ def test_full_size_properties_bf16():
     assert torch.isfinite(a).all() and a.abs().max().item() < 1.5            # x0 is clipped to [-1, 1]; the last step adds sqrt(1 - a_0) eps
     sub = gd.ddim_sample(net, 256, batch_size=4, ddim_timesteps=4, x_T=xT[8:12], return_tensor=True)
     assert torch.equal(sub, a[8:12])
+
+
+def test_ddim_fp32_at_256_vs_cpu_oracle():
+    """The north-star parity statement at the headline RESOLUTION: default UNetModel, 1x3x256x256, 10-step DDIM (cosine),
+    fp32 HIP path vs the CPU oracle run here on the same weights and start noise: <= 1e-3 per pixel; the per-forward
+    eps error is checked on the way (1e-4).  (The oracle is pinned at 64x64 by the reference's golden vectors; at 256 it is
+    the same code on a larger grid.)"""
+    from oracle import lineage_b as ob
+    from advshadow_amd.diff_model import GaussianDiffusion
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    hp = ob.hparams()
+    sd = ob.init_state_dict(0, hp)
+    torch.manual_seed(0)
+    net = UNetModel().to("cuda").eval()
+    for k, v in net.state_dict().items():
+        assert torch.equal(v.cpu(), sd[k]), k                          # same seeded construction
+    g = torch.Generator().manual_seed(77)
+    xT = torch.randn(1, 3, 256, 256, generator=g)
+    t = torch.full((1,), 901, dtype=torch.long)
+    eps_ref = ob.unet_forward(sd, hp, xT, t)
+    eps = net(xT.cuda(), t.cuda()).cpu()
+    assert (eps - eps_ref).abs().max().item() < 1e-4
+    ref = ob.ddim_sample(lambda x, tt: ob.unet_forward(sd, hp, x, tt), xT, steps=10)
+    out = GaussianDiffusion().ddim_sample(net, 256, batch_size=1, ddim_timesteps=10, x_T=xT, return_tensor=True).cpu()
+    assert (out - ref).abs().max().item() < 1e-3
