@@ -68,6 +68,8 @@ SIGNATURES = {
     "advs_to_uint8": [vp, vp, sz, i32, vp],
     "advs_unit_to_uint8": [vp, vp, sz, vp],
     "advs_apply_shadow": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, C.POINTER(f32), i32, vp],
+    "advs_apply_shadow_parts": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, C.POINTER(f32), i32, vp],
+    "advs_blend_mask_clamp01": [vp, vp, vp, vp, C.c_longlong, vp],
     "advs_composite_u8": [vp, vp, vp, vp, sz, i32, f32, vp],
     "advs_resample_u8": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "advs_u8hwc_to_f32nchw": [vp, vp, i32, i32, i32, i32, vp, vp, vp],
@@ -78,6 +80,15 @@ SIGNATURES = {
     "advs_conv_stem": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "advs_maxpool3x3s2": [vp, vp, i32, i32, i32, i32, i32, vp],
     "advs_global_avgpool": [vp, vp, i32, i32, i32, i32, vp],
+    "advs_softmax_ce_grad": [vp, vp, vp, i32, i32, f32, vp],
+    "advs_relu_bwd": [vp, vp, vp, vp, C.c_longlong, i32, vp],
+    "advs_zero_insert2x": [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    "advs_avgpool_bwd_relu": [vp, vp, vp, i32, i32, i32, i32, vp],
+    "advs_maxpool3x3s2_bwd_relu": [vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "advs_conv_stem_bwd": [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "advs_iga_step": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, f32, vp],
+    "advs_perturb_clamp01": [vp, vp, vp, C.c_longlong, vp],
+    "advs_lerp_stack": [vp, vp, vp, i32, C.c_longlong, vp],
     "advs_graph_begin": [vp],
     "advs_graph_end": [vp, C.POINTER(vp)],
     "advs_graph_launch": [vp, vp],

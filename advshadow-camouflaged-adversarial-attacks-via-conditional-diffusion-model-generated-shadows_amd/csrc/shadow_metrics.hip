@@ -12,6 +12,7 @@
 // Traffic: reads C+Cm planes, writes C planes of H*W f32.
 struct ShadowP {
     const float* img; const float* fmask; const float* centers; const float* radii; float* out;
+    float* shadowed; float* cmask;                // optional [B][C][H][W]: sh (not clamped) and cm, for the gradient attack
     int B, C, H, W, Cm, K;
     float intensity;
     float taps[7];
@@ -51,25 +52,61 @@ __global__ void apply_shadow_kernel(const ShadowP p) {
             const float keep = v * (1.f - cm);
             const float sh = keep + cm * (v * (1.f - p.intensity));
             const float o = keep + sh * cm;
-            p.out[((size_t)b * p.C + c) * hw + rem] = fminf(fmaxf(o, 0.f), 1.f);
+            if (p.out) p.out[((size_t)b * p.C + c) * hw + rem] = fminf(fmaxf(o, 0.f), 1.f);
+            if (p.shadowed) p.shadowed[((size_t)b * p.C + c) * hw + rem] = sh;
+            if (p.cmask) p.cmask[((size_t)b * p.C + c) * hw + rem] = cm;
         }
     }
 }
 
-extern "C" int advs_apply_shadow(const float* img, const float* feature_mask, const float* centers, const float* radii,
-                                 float* out, int b, int c, int h, int w, int mask_channels, float intensity,
-                                 const float* taps, int ntaps, void* stream) {
-    ADVS_REQUIRE(img && feature_mask && centers && radii && out && b > 0 && c > 0 && h > 0 && w > 0, "apply_shadow: bad args");
+static int apply_shadow_launch(const float* img, const float* feature_mask, const float* centers, const float* radii,
+                               float* out, float* shadowed, float* cmask, int b, int c, int h, int w, int mask_channels,
+                               float intensity, const float* taps, int ntaps, void* stream) {
+    ADVS_REQUIRE(img && feature_mask && centers && radii && (out || (shadowed && cmask)) && b > 0 && c > 0 && h > 0 && w > 0, "apply_shadow: bad args");
     ADVS_REQUIRE(mask_channels == 1 || mask_channels == c, "apply_shadow: feature mask must have 1 or %d channels", c);
     ADVS_REQUIRE(ntaps >= 1 && ntaps <= 7 && (ntaps & 1) && taps, "apply_shadow: blur kernel size %d unsupported", ntaps);
     ShadowP p;
     p.img = img; p.fmask = feature_mask; p.centers = centers; p.radii = radii; p.out = out;
+    p.shadowed = shadowed; p.cmask = cmask;
     p.B = b; p.C = c; p.H = h; p.W = w; p.Cm = mask_channels; p.K = ntaps; p.intensity = intensity;
     for (int i = 0; i < 7; ++i) p.taps[i] = i < ntaps ? taps[i] : 0.f;
     const size_t total = (size_t)b * h * w;
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     apply_shadow_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(p);
     ADVS_CHECK_LAUNCH("apply_shadow");
+    return ADVS_OK;
+}
+
+extern "C" int advs_apply_shadow(const float* img, const float* feature_mask, const float* centers, const float* radii,
+                                 float* out, int b, int c, int h, int w, int mask_channels, float intensity,
+                                 const float* taps, int ntaps, void* stream) {
+    ADVS_REQUIRE(out, "apply_shadow: bad args");
+    return apply_shadow_launch(img, feature_mask, centers, radii, out, nullptr, nullptr, b, c, h, w, mask_channels, intensity, taps, ntaps, stream);
+}
+
+// The two intermediates the gradient attack needs (train_shadow.py:250-256): shadowed image (not clamped) and the
+// combined mask cm, both [b][c][h][w].
+extern "C" int advs_apply_shadow_parts(const float* img, const float* feature_mask, const float* centers, const float* radii,
+                                       float* shadowed, float* cmask, int b, int c, int h, int w, int mask_channels,
+                                       float intensity, const float* taps, int ntaps, void* stream) {
+    ADVS_REQUIRE(shadowed && cmask, "apply_shadow_parts: bad args");
+    return apply_shadow_launch(img, feature_mask, centers, radii, nullptr, shadowed, cmask, b, c, h, w, mask_channels, intensity, taps, ntaps, stream);
+}
+
+// out = clamp(img * (1 - cm) + adv * cm, 0, 1)    (train_shadow.py:262-265)
+__global__ void blend_mask_clamp01_kernel(const float* __restrict__ img, const float* __restrict__ adv, const float* __restrict__ cm,
+                                          float* __restrict__ out, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float m = cm[i];
+        out[i] = fminf(fmaxf(img[i] * (1.f - m) + adv[i] * m, 0.f), 1.f);
+    }
+}
+
+extern "C" int advs_blend_mask_clamp01(const float* img, const float* adv, const float* cmask, float* out, long long n, void* stream) {
+    ADVS_REQUIRE(img && adv && cmask && out && n > 0, "blend_mask_clamp01: bad args");
+    const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    blend_mask_clamp01_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(img, adv, cmask, out, (size_t)n);
+    ADVS_CHECK_LAUNCH("blend_mask_clamp01");
     return ADVS_OK;
 }
 

@@ -2,9 +2,9 @@
 
 * ``apply_shadow`` — tensor form, closed-form part of tools/train_shadow.py:224-266 (variants
   ddim2/diff_model2.py:615-654 without blur, ddim2/test.py:830-871 with intensity 0.051): circular
-  shadow mask, 5x5 Gaussian softening, feature-mask intersection, darkening, clamp.  The gradient
-  attack the reference interleaves (``apply_adversarial_perturbation``) needs autograd through the
-  victim and is out of scope: ``classifier`` must be ``None``.
+  shadow mask, 5x5 Gaussian softening, feature-mask intersection, darkening, clamp.  With a
+  ``classifier`` the gradient attack the reference interleaves (``apply_adversarial_perturbation``) runs on the
+  victim's HIP backward plan (``adversarial.py``); with ``classifier=None`` the closed form alone.
 * ``add_shadow`` — add_shadow.py:35-60 as a function: triangle shadow in the bounding box of the
   mask's largest blob, ``Image.alpha_composite`` then ``Image.composite`` through the mask.
 * ``add_shadow_to_mask_area`` — shadow_for_attack.py:22-93.
@@ -57,14 +57,18 @@ def apply_shadow_batch(images, centers, radii, feature_masks, shadow_intensity=0
 def apply_shadow(image, shadow_center, shadow_radius, feature_mask, classifier=None, target_label=None, device=None,
                  shadow_intensity=0.43, epsilon=0.01, blur_kernel_size=5):
     """Reference signature (tools/train_shadow.py:224-225).  image [C,H,W] in [0,1]."""
-    if classifier is not None:
-        raise NotImplementedError("the gradient-based perturbation inside apply_shadow (train_shadow.py:177-221) is "
-                                  "outside the hot path; pass classifier=None for the closed-form shadow")
     dev = torch.device(device) if device is not None else (image.device if image.is_cuda else torch.device("cuda"))
     img = image.to(dev)[None]
     fm = feature_mask.to(dev)
     fm = fm[None] if fm.dim() == 3 else fm[None, None]
     ctr = torch.as_tensor([float(shadow_center[0]), float(shadow_center[1])])[None]
+    if classifier is not None:
+        from .adversarial import apply_shadow_adversarial_batch
+        if target_label is None:
+            raise ValueError("apply_shadow: a classifier needs target_label (train_shadow.py:259)")
+        return apply_shadow_adversarial_batch(classifier, img, ctr, torch.as_tensor([float(shadow_radius)]), fm,
+                                              torch.as_tensor(target_label).reshape(1), shadow_intensity, epsilon,
+                                              blur_kernel_size)[0]
     return apply_shadow_batch(img, ctr, torch.as_tensor([float(shadow_radius)]), fm, shadow_intensity, blur_kernel_size)[0]
 
 

@@ -79,7 +79,7 @@ class ResNet50(nn.Module):
                 W[p + ".wd"], W[p + ".bd"] = pack_conv_weight(w, dt), b
         W["fc.w"], W["fc.b"] = sd["fc.weight"].float().contiguous(), sd["fc.bias"].float().contiguous()
         self._packed[dt] = (ver, W)
-        for key in [k for k in self._engines if k[2] == dt]:
+        for key in [k for k in self._engines if k[-1] == dt]:
             del self._engines[key]
         return W
 
@@ -91,6 +91,55 @@ class ResNet50(nn.Module):
             eng = _ResNetEngine(self, W, batch, size, dt)
             self._engines[(batch, size, dt)] = eng
         return eng
+
+    def packed_grad_weights(self, dt):
+        """Weights of the data-gradient convs: 1x1 transposed, 3x3 transposed and flipped (BatchNorm folded as in the
+        forward), the classifier weight transposed."""
+        ver = self._version()
+        hit = self._packed.get(("grad", dt))
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        self.packed_weights(dt)                              # device check + cache invalidation of the engines
+        sd = {k: v.detach() for k, v in self.state_dict().items()}
+        G = {}
+        for p, cin, width, cout, s, ds in self.blocks:
+            for i in ("1", "2", "3"):
+                w, _ = self._fold(sd, f"{p}.conv{i}", f"{p}.bn{i}")
+                G[f"{p}.w{i}T"] = pack_conv_weight(w.permute(1, 0, 2, 3).flip(2, 3).contiguous(), dt)
+            if ds:
+                w, _ = self._fold(sd, p + ".downsample.0", p + ".downsample.1")
+                G[p + ".wdT"] = pack_conv_weight(w.permute(1, 0, 2, 3).contiguous(), dt)
+        G["fc.wT"] = sd["fc.weight"].float().t().contiguous()
+        self._packed[("grad", dt)] = (ver, G)
+        return G
+
+    def grad_engine(self, batch, size, dtype=None):
+        """Static plan of forward + backward-to-the-image (d cross_entropy / d x) for [batch,3,size,size] inputs."""
+        dt = dtype_code(dtype if dtype is not None else self.compute_dtype)
+        W, G = self.packed_weights(dt), self.packed_grad_weights(dt)
+        eng = self._engines.get(("grad", batch, size, dt))
+        if eng is None:
+            eng = _ResNetGradEngine(self, W, G, batch, size, dt)
+            self._engines[("grad", batch, size, dt)] = eng
+        return eng
+
+    def input_gradient(self, x, labels):
+        """x [B,3,H,W] f32, labels [B] int64 (GPU) -> (logits [B,K], d cross_entropy(logits_b, label_b) / d x_b [B,3,H,W]):
+        what ``loss.backward(); image.grad`` yields for a batch of one in tools/train_shadow.py:204-212, per image."""
+        B, _, H, Wd = x.shape
+        assert H == Wd, "square inputs only"
+        eng = self.grad_engine(B, H)
+        cur = torch.cuda.current_stream(x.device)
+        eng.stream.wait_stream(cur)
+        with torch.cuda.stream(eng.stream):
+            eng.x.copy_(x.to(torch.float32), non_blocking=True)
+            eng.labels.copy_(labels.to(torch.int64).reshape(B), non_blocking=True)
+            eng.run()
+            out, grad = eng.logits.clone(), eng.grad.clone()
+        cur.wait_stream(eng.stream)
+        out.record_stream(cur)
+        grad.record_stream(cur)
+        return out, grad
 
     def forward(self, x):
         """x [B,3,H,W] f32 on the GPU -> logits [B,num_classes] f32."""
@@ -150,6 +199,97 @@ class _ResNetEngine:
             self.plan.capture()
             self.captured = True
         self.plan.run()
+
+
+class _ResNetGradEngine:
+    """Forward with every post-ReLU activation retained, then the network backwards down to the image.
+
+    Backward of one bottleneck, with G = d loss / d (pre-ReLU block output), already masked by the block's ReLU:
+      g2 = conv1x1(G, w3^T) * [y2 > 0];  g1 = conv3x3(zero_insert(g2), flip(w2)^T) * [y1 > 0];
+      d h = conv1x1(g1, w1^T) + (downsample ? zero_insert(conv1x1(G, wd^T)) : G);  next G = d h * [h > 0].
+    BatchNorm is folded into the conv weights exactly as in the forward, so its backward is the folded conv's."""
+
+    def __init__(self, model, W, G, batch, size, dt):
+        dev = next(model.parameters()).device
+        self.model, self.stream = model, torch.cuda.Stream(device=dev)
+        with torch.cuda.device(dev):
+            bld = Builder(dev, dt, self.stream, batch)
+            lib, plan = bld.lib, bld.plan
+            self.x = torch.zeros((batch, 3, size, size), dtype=torch.float32, device=dev)
+            self.labels = torch.zeros((batch,), dtype=torch.int64, device=dev)
+            self.grad = torch.zeros((batch, 3, size, size), dtype=torch.float32, device=dev)
+            # ---- forward (as _ResNetEngine, nothing released)
+            ho = (size + 6 - 7) // 2 + 1
+            stem = bld.buf((batch, ho, ho, 64))
+            plan.add(lib.advs_conv_stem, ptr(self.x), ptr(W["stem.w"]), ptr(W["stem.b"]), ptr(stem), batch, 3, size, size,
+                     64, 7, 2, 3, _lib.ACT["relu"], dt, keep=(self.x, stem))
+            hp = (ho + 2 - 3) // 2 + 1
+            h = bld.buf((batch, hp, hp, 64))
+            plan.add(lib.advs_maxpool3x3s2, ptr(stem), ptr(h), batch, ho, ho, 64, dt, keep=(stem, h))
+            acts = []
+            for p, cin, width, cout, s, ds in model.blocks:
+                y1 = bld.conv(h, W[p + ".w1"], width, bias=W[p + ".b1"], ksize=1, pad=0, act="relu")
+                y2 = bld.conv(y1, W[p + ".w2"], width, bias=W[p + ".b2"], ksize=3, stride=s, pad=1, act="relu")
+                idn = bld.conv(h, W[p + ".wd"], cout, bias=W[p + ".bd"], ksize=1, stride=s, pad=0) if ds else h
+                y3 = bld.conv(y2, W[p + ".w3"], cout, bias=W[p + ".b3"], residual=idn, ksize=1, pad=0, act="relu")
+                if idn is not h:
+                    bld.free(idn)
+                acts.append((h, y1, y2, y3))
+                h = y3
+            _, hh, ww, cc = h.shape
+            pooled = bld.buf((batch, cc), torch.float32)
+            plan.add(lib.advs_global_avgpool, ptr(h), ptr(pooled), batch, hh * ww, cc, dt, keep=(h, pooled))
+            self.logits = bld.linear(pooled, W["fc.w"], W["fc.b"])
+            # ---- backward
+            K = self.logits.shape[1]
+            gl = bld.buf((batch, K), torch.float32)
+            plan.add(lib.advs_softmax_ce_grad, ptr(self.logits), ptr(self.labels), ptr(gl), batch, K, 1.0,
+                     keep=(self.logits, self.labels, gl))
+            gp = bld.linear(gl, G["fc.wT"], None)
+            g = bld.buf(tuple(h.shape))
+            plan.add(lib.advs_avgpool_bwd_relu, ptr(gp), ptr(h), ptr(g), batch, hh * ww, cc, dt, keep=(gp, h, g))
+
+            def relu_bwd(t, y):
+                plan.add(lib.advs_relu_bwd, ptr(t), 0, ptr(y), ptr(t), t.numel(), dt, keep=(t, y))
+
+            def zero_insert(t, like):
+                z = bld.buf((batch, like.shape[1], like.shape[2], t.shape[3]))
+                plan.add(lib.advs_zero_insert2x, ptr(t), ptr(z), batch, t.shape[1], t.shape[2], t.shape[3], like.shape[1],
+                         like.shape[2], dt, keep=(t, z))
+                bld.free(t)
+                return z
+
+            for (p, cin, width, cout, s, ds), (hin, y1, y2, y3) in zip(reversed(model.blocks), reversed(acts)):
+                g2 = bld.conv(g, G[p + ".w3T"], width, ksize=1, pad=0)
+                relu_bwd(g2, y2)
+                if s == 2:
+                    g2 = zero_insert(g2, y1)
+                g1 = bld.conv(g2, G[p + ".w2T"], width, ksize=3, stride=1, pad=1)
+                relu_bwd(g1, y1)
+                bld.free(g2)
+                if ds:
+                    res = bld.conv(g, G[p + ".wdT"], cin, ksize=1, pad=0)
+                    if s == 2:
+                        res = zero_insert(res, hin)
+                    bld.free(g)
+                else:
+                    res = g
+                gh = bld.conv(g1, G[p + ".w1T"], cin, residual=res, ksize=1, pad=0)
+                bld.free(g1)
+                bld.free(res)
+                if hin is not acts[0][0]:                      # the first block reads the max-pooled stem: its ReLU is
+                    relu_bwd(gh, hin)                          # applied by advs_maxpool3x3s2_bwd_relu below
+                for t in (y1, y2, y3):
+                    bld.free(t)
+                g = gh
+            gs = bld.buf(tuple(stem.shape))
+            plan.add(lib.advs_maxpool3x3s2_bwd_relu, ptr(g), ptr(stem), ptr(gs), batch, ho, ho, 64, dt, keep=(g, stem, gs))
+            plan.add(lib.advs_conv_stem_bwd, ptr(gs), ptr(W["stem.w"]), ptr(self.grad), batch, 3, size, size, 64, 7, 2, 3, dt,
+                     keep=(gs, self.grad))
+            self.plan, self.captured = plan, False
+            torch.cuda.synchronize(dev)
+
+    run = _ResNetEngine.run
 
 
 # ============================================================================ ViT (HF ViTForImageClassification)

@@ -231,6 +231,14 @@ int advs_unit_to_uint8(const float* x, uint8_t* y, size_t n, void* stream);
 int advs_apply_shadow(const float* img, const float* feature_mask, const float* centers, const float* radii,
                       float* out, int b, int c, int h, int w, int mask_channels, float intensity,
                       const float* taps, int ntaps, void* stream);
+/* The same composite stopped half way, for the gradient attack of train_shadow.py:250-260: the shadowed image (NOT
+ * clamped) and the combined mask cm = blur(shadow mask) * feature mask, both [b][c][h][w] f32.                     */
+int advs_apply_shadow_parts(const float* img, const float* feature_mask, const float* centers, const float* radii,
+                            float* shadowed, float* cmask, int b, int c, int h, int w, int mask_channels,
+                            float intensity, const float* taps, int ntaps, void* stream);
+/* out = clamp(img * (1 - cm) + adv * cm, 0, 1)  (train_shadow.py:262-265), n f32 elements each.                      */
+int advs_blend_mask_clamp01(const float* img, const float* adv, const float* cmask, float* out, long long n, void* stream);
+
 /* Pillow-exact uint8 composites on [npix] RGB pixels with an RGBA layer and an L mask.
  * mode 0: Image.composite(Image.alpha_composite(img, layer), img, mask)      (add_shadow.py:57-58)
  * mode 1: add_shadow_to_mask_area + adjust_shadow_brightness(factor)  (shadow_for_attack.py:50-93) */
@@ -273,6 +281,35 @@ int advs_conv_stem(const float* x_nchw, const float* w_oihw, const float* bias, 
                    int dtype, void* stream);
 int advs_maxpool3x3s2(const void* x, void* y, int b, int h, int w, int c, int dtype, void* stream); /* MaxPool2d(3,2,1) */
 int advs_global_avgpool(const void* x, float* y, int b, int hw, int c, int dtype, void* stream);    /* -> f32 [b][c] */
+
+/* ---- input gradient of the victim (gradient-based perturbation inside apply_shadow: tools/train_shadow.py:177-221
+ * apply_adversarial_perturbation, 20 x { loss = cross_entropy(model(image + perturbation), label); loss.backward();
+ * perturbation -= alpha * sign(image.grad * mask) }, and its integrated-gradient variant ddim2/test.py:647-681).
+ * d loss / d image of the eval-mode ResNet-50 runs the network backwards: each conv's data gradient is advs_conv2d on
+ * transposed / flipped weights (stride 2: advs_zero_insert2x first); the rest are the entry points below.  NHWC T
+ * activations as in the forward, f32 NCHW at the image end.                                                        */
+/* out[b][k] = scale * (softmax(logits[b])[k] - [k == labels[b]])  -- d cross_entropy / d logits (labels int64)     */
+int advs_softmax_ce_grad(const float* logits, const long long* labels, float* out, int b, int k, float scale, void* stream);
+/* out = y > 0 ? g + add : 0; y = forward activation after its ReLU; add may be NULL; out may alias g.  n elements.   */
+int advs_relu_bwd(const void* g, const void* add, const void* y, void* out, long long n, int dtype, void* stream);
+/* out[b][2i][2j] = in[b][i][j], zero elsewhere; out is [b][ho][wo][c] with ho in {2h-1, 2h} (likewise wo).           */
+int advs_zero_insert2x(const void* in, void* out, int b, int h, int w, int c, int ho, int wo, int dtype, void* stream);
+/* out[b][p][c] = y[b][p][c] > 0 ? gp[b][c] / hw : 0  (AdaptiveAvgPool2d(1) backward + the last block's ReLU)         */
+int advs_avgpool_bwd_relu(const float* gp, const void* y, void* out, int b, int hw, int c, int dtype, void* stream);
+/* MaxPool2d(3,2,1) backward (first maximum of a window gets its gradient, as torch) times [x > 0]; x [b][h][w][c] is
+ * the pool's input (the stem output after ReLU), g the gradient at the pooled resolution.                            */
+int advs_maxpool3x3s2_bwd_relu(const void* g, const void* x, void* out, int b, int h, int w, int c, int dtype, void* stream);
+/* data gradient of advs_conv_stem: g NHWC T [b][ho][wo][cout], w the same f32 OIHW weight -> dx NCHW f32 [b][cin][h][w] */
+int advs_conv_stem_bwd(const void* g, const float* w_oihw, float* dx_nchw, int b, int cin, int h, int w, int cout,
+                       int ksize, int stride, int pad, int dtype, void* stream);
+/* pert = clamp(pert - alpha * sign(sum_k grad[b][k] * mask), -eps, eps); x_in = x0 + pert (x_in may be NULL).
+ * x0, pert, x_in NCHW f32 [b][c][hw]; grad [b][nsum][c][hw]; mask [b][mask_channels (1 | c)][hw].                   */
+int advs_iga_step(const float* x0, const float* grad, const float* mask, float* pert, float* x_in,
+                  int b, int c, int hw, int mask_channels, int nsum, float alpha, float eps, void* stream);
+/* out = clamp(x0 + pert, 0, 1)   (train_shadow.py:219-220)                                                          */
+int advs_perturb_clamp01(const float* x0, const float* pert, float* out, long long n, void* stream);
+/* out[k] = base + (k / steps) * (x - base), k = 0..steps, stacked [steps+1][n]  (ddim2/test.py:659-660)            */
+int advs_lerp_stack(const float* base, const float* x, float* out, int steps, long long n, void* stream);
 
 /* DINOv2's classifier input (Dinov2ForImageClassification.forward; HF checkpoints of ASR_fast.py:47-58):
  * y[b] = [ tokens[b][0] | mean(tokens[b][1..np]) ], tokens [b][n_pad][c] -> y [b][2c] f32.                        */

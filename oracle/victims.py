@@ -16,8 +16,8 @@ def _bn(sd, p, x):
                         training=False, eps=1e-5)
 
 
-@torch.no_grad()
-def resnet50_forward(sd, x):
+def resnet50_logits(sd, x):
+    """The forward with autograd left on (oracle/adversarial.py differentiates it with respect to x)."""
     h = F.relu(_bn(sd, "bn1", F.conv2d(x, sd["conv1.weight"], stride=2, padding=3)))
     h = F.max_pool2d(h, 3, 2, 1)
     for li, (width, n, stride) in enumerate(LAYERS, start=1):
@@ -32,6 +32,11 @@ def resnet50_forward(sd, x):
             h = F.relu(o + h)
     h = F.adaptive_avg_pool2d(h, 1).flatten(1)
     return F.linear(h, sd["fc.weight"], sd["fc.bias"])
+
+
+@torch.no_grad()
+def resnet50_forward(sd, x):
+    return resnet50_logits(sd, x)
 
 
 def randomize_bn(sd, seed):

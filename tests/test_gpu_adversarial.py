@@ -1,0 +1,203 @@
+"""Gradient-based perturbation (tools/train_shadow.py:76-266, ddim2/test.py:647-681) on the MI355X vs CPU autograd.
+
+The oracle differentiates the functional ResNet-50 with torch autograd; the HIP path runs the network backwards with
+its own kernels.  fp32 tolerance on gradients: 1e-3 of the largest component (written next to each assert); sign
+updates are compared as the fraction of pixels that agree, because a gradient component within rounding of zero may
+legitimately take either sign.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from gpu_helpers import OneOp, dev, nchw, nhwc  # noqa: E402
+from advshadow_amd import adversarial, shadow  # noqa: E402
+from advshadow_amd.engine import ptr  # noqa: E402
+from oracle import adversarial as oa  # noqa: E402
+from test_gpu_victim_asr import make_victim  # noqa: E402
+
+
+def test_softmax_ce_grad_matches_autograd():
+    g = torch.Generator().manual_seed(0)
+    logits = (torch.randn(5, 37, generator=g) * 3).requires_grad_(True)
+    labels = torch.tensor([0, 36, 5, 5, 17])
+    F.cross_entropy(logits, labels, reduction="sum").backward()
+    op = OneOp("fp32", 5)
+    ld, lab = logits.detach().to(dev()), labels.to(dev())
+    out = torch.empty(5, 37, device=dev())
+    op.b.plan.add(op.b.lib.advs_softmax_ce_grad, ptr(ld), ptr(lab), ptr(out), 5, 37, 1.0)
+    op.go()
+    assert (out.cpu() - logits.grad).abs().max().item() < 1e-6
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("hw", [(37, 41), (16, 16)])
+def test_maxpool_backward_with_relu(dt, hw):
+    g = torch.Generator().manual_seed(1)
+    z = torch.randn(2, 64, *hw, generator=g)
+    if dt == "bf16":
+        z = z.bfloat16().float()
+    z.requires_grad_(True)
+    y = F.max_pool2d(F.relu(z), 3, 2, 1)
+    gy = torch.randn(y.shape, generator=g)
+    if dt == "bf16":
+        gy = gy.bfloat16().float()
+    y.backward(gy)
+    op = OneOp(dt, 2)
+    xd, gd = nhwc(F.relu(z.detach()), op.b.tdt), nhwc(gy, op.b.tdt)
+    out = op.b.buf((2, hw[0], hw[1], 64))
+    op.b.plan.add(op.b.lib.advs_maxpool3x3s2_bwd_relu, ptr(gd), ptr(xd), ptr(out), 2, hw[0], hw[1], 64, op.b.dt)
+    op.go()
+    tol = 1e-6 if dt == "fp32" else 4e-2          # bf16: a pixel may collect up to four rounded gradients
+    assert (nchw(out) - z.grad).abs().max().item() < tol
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_stem_data_gradient(dt):
+    g = torch.Generator().manual_seed(2)
+    x = torch.rand(2, 3, 37, 41, generator=g, requires_grad=True)
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.05
+    y = F.conv2d(x, w, stride=2, padding=3)
+    gy = torch.randn(y.shape, generator=g)
+    if dt == "bf16":
+        gy = gy.bfloat16().float()
+    y.backward(gy)
+    op = OneOp(dt, 2)
+    gd, wd = nhwc(gy, op.b.tdt), w.to(dev())
+    dx = torch.empty(2, 3, 37, 41, device=dev())
+    op.b.plan.add(op.b.lib.advs_conv_stem_bwd, ptr(gd), ptr(wd), ptr(dx), 2, 3, 37, 41, 64, 7, 2, 3, op.b.dt)
+    op.go()
+    assert (dx.cpu() - x.grad).abs().max().item() < 2e-5 * x.grad.abs().max().item() + 1e-5
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_zero_insert_and_relu_backward(dt):
+    g = torch.Generator().manual_seed(3)
+    op = OneOp(dt, 2)
+    a = torch.randn(2, 64, 5, 4, generator=g)
+    ad = nhwc(a, op.b.tdt)
+    z = op.b.buf((2, 9, 8, 64))
+    op.b.plan.add(op.b.lib.advs_zero_insert2x, ptr(ad), ptr(z), 2, 5, 4, 64, 9, 8, op.b.dt)
+    gr, add, y = (torch.randn(2, 64, 9, 8, generator=g) for _ in range(3))
+    grd, addd, yd = (nhwc(t, op.b.tdt) for t in (gr, add, y))
+    out = op.b.buf((2, 9, 8, 64))
+    op.b.plan.add(op.b.lib.advs_relu_bwd, ptr(grd), ptr(addd), ptr(yd), ptr(out), out.numel(), op.b.dt)
+    op.go()
+    ref = torch.zeros(2, 64, 9, 8)
+    ref[:, :, ::2, ::2] = nchw(ad)
+    assert torch.equal(nchw(z), ref)
+    f = (lambda t: t.bfloat16().float()) if dt == "bf16" else (lambda t: t)
+    refb = torch.where(f(y) > 0, f(gr) + f(add), torch.zeros(()))
+    assert (nchw(out) - refb).abs().max().item() < (1e-6 if dt == "fp32" else 4e-2)
+
+
+@pytest.mark.parametrize("size,batch", [(64, 2), (72, 1)])
+def test_input_gradient_fp32_matches_autograd(size, batch):
+    """Whole network: 72 exercises the odd stride-2 pre-images (9 -> 5 -> 3)."""
+    net, sd = make_victim(seed=3)
+    g = torch.Generator().manual_seed(size)
+    x = torch.rand(batch, 3, size, size, generator=g)
+    labels = torch.randint(0, 37, (batch,), generator=g)
+    ref_logits, ref = oa.input_gradient(sd, x, labels)
+    logits, grad = net.input_gradient(x.to(dev()), labels.to(dev()))
+    assert (logits.cpu() - ref_logits).abs().max().item() < 1e-3
+    scale = ref.abs().max().item()
+    assert scale > 0
+    assert (grad.cpu() - ref).abs().max().item() < 1e-3 * scale          # fp32 parity bar
+    # per-image gradients: an image's result does not depend on its batch
+    if batch > 1:
+        _, g0 = net.input_gradient(x[:1].to(dev()), labels[:1].to(dev()))
+        assert torch.equal(g0.cpu(), grad[:1].cpu())
+
+
+def test_input_gradient_replays_bit_identically_and_bf16_agrees():
+    net, sd = make_victim(seed=4)
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(2, 3, 64, 64, generator=g).to(dev())
+    labels = torch.tensor([3, 30], device=dev())
+    _, a = net.input_gradient(x, labels)
+    _, b = net.input_gradient(x, labels)
+    assert torch.equal(a, b)
+    net16, _ = make_victim(seed=4, compute_dtype="bf16")
+    _, c = net16.input_gradient(x, labels)
+    cos = F.cosine_similarity(a.flatten(1), c.flatten(1)).min().item()
+    assert cos > 0.9, cos                     # bf16 storage of 50 layers of activations and gradients: direction kept
+
+
+def _mask(size, seed):
+    g = torch.Generator().manual_seed(seed)
+    m = torch.zeros(1, size, size)
+    m[:, size // 4: 3 * size // 4, size // 8: 7 * size // 8] = 1.0
+    return m * (torch.rand(1, size, size, generator=g) > 0.1).float()
+
+
+def test_iterative_gradient_attack_matches_oracle():
+    net, sd = make_victim(seed=5)
+    g = torch.Generator().manual_seed(11)
+    img = torch.rand(3, 64, 64, generator=g)
+    label = torch.tensor([7])
+    m = _mask(64, 1)
+    grads = []
+    ref, ref_pert = oa.apply_adversarial_perturbation(sd, img, label, m, epsilon=0.02, alpha=0.005, iterations=6, grads=grads)
+    got = adversarial.apply_adversarial_perturbation(net, img, label, dev(), m, epsilon=0.02, alpha=0.005, iterations=6).cpu()
+    _, pert = adversarial.adversarial_perturbation_batch(net, img[None].to(dev()), label, m, 0.02, 0.005, 6)
+    pert = pert[0].cpu()
+    assert pert.abs().max().item() <= 0.02 + 1e-7 and torch.equal(pert * (1 - m), torch.zeros_like(pert))
+    assert torch.equal(got, torch.clamp(img + pert, 0, 1))
+    agree = (pert - ref_pert).abs() < 1e-6
+    assert agree.float().mean().item() > 0.97, agree.float().mean().item()
+    assert (got - ref).abs().max().item() <= 2 * 0.02 + 1e-6
+    # first iteration (identical inputs): wherever the oracle's gradient is clearly non-zero the signs agree
+    _, g1 = net.input_gradient(img[None].to(dev()), label.to(dev()))
+    g1 = g1[0].cpu() * m
+    clear = grads[0].abs() > 1e-3 * grads[0].abs().max()
+    assert torch.equal(g1.sign()[clear], grads[0].sign()[clear])
+
+
+def test_batched_attack_equals_one_image_at_a_time():
+    net, _ = make_victim(seed=5)
+    g = torch.Generator().manual_seed(12)
+    imgs = torch.rand(3, 3, 64, 64, generator=g).to(dev())
+    labels = torch.tensor([1, 2, 3])
+    masks = torch.stack([_mask(64, i) for i in range(3)])
+    out, _ = adversarial.adversarial_perturbation_batch(net, imgs, labels, masks, 0.03, 0.005, 4)
+    for i in range(3):
+        one, _ = adversarial.adversarial_perturbation_batch(net, imgs[i:i + 1], labels[i:i + 1], masks[i:i + 1], 0.03, 0.005, 4)
+        assert torch.equal(one[0], out[i])
+
+
+def test_integrated_gradient_variant_matches_oracle():
+    net, sd = make_victim(seed=6)
+    g = torch.Generator().manual_seed(13)
+    img, base = torch.rand(3, 64, 64, generator=g), torch.randn(3, 64, 64, generator=g)
+    label, m = torch.tensor([20]), _mask(64, 2)
+    ref, ref_pert, ig = oa.integrated_gradient_perturbation(sd, img, label, m, base, epsilon=0.5, alpha=0.005, iterations=3, steps=4)
+    got, shown = adversarial.integrated_gradient_perturbation(net, img, label, dev(), m, epsilon=0.5, alpha=0.005,
+                                                              iterations=3, steps=4, baseline=base)
+    pert = got.cpu() - img                                     # no clamp active where img in (0.02, 0.98)
+    inner = (img > 0.02) & (img < 0.98)
+    agree = ((pert - ref_pert).abs() < 1e-6) | ~inner
+    assert agree.float().mean().item() > 0.97, agree.float().mean().item()
+    assert (got.cpu() - ref).abs().max().item() <= 2 * 0.005 * sum((i + 1) ** -0.5 for i in range(3)) + 1e-6
+    assert shown.shape == (64, 64, 3) and 0.0 <= shown.min() and shown.max() <= 1.0
+
+
+def test_apply_shadow_with_classifier_and_position_search():
+    net, sd = make_victim(seed=7)
+    g = torch.Generator().manual_seed(14)
+    img = torch.rand(3, 64, 64, generator=g)
+    label, m = torch.tensor([11]), _mask(64, 3)
+    ref = oa.apply_shadow(sd, img, (30.0, 34.0), 14.0, m, label)
+    got = shadow.apply_shadow(img, (30.0, 34.0), 14.0, m, classifier=net, target_label=label, device=dev()).cpu()
+    assert ((got - ref).abs() < 1e-6).float().mean().item() > 0.97
+    assert (got - ref).abs().max().item() <= 2 * 0.01 + 1e-6
+    plain = shadow.apply_shadow(img, (30.0, 34.0), 14.0, m, device=dev()).cpu()
+    assert (got - plain).abs().max().item() <= 0.01 + 1e-6      # the attack moves a pixel by at most epsilon * cm
+    # optimize_shadow_position: centre / radius identical to the reference's Adam step, image as above
+    c_ref, r_ref, im_ref = oa.optimize_shadow_position(sd, img, m, label, iterations=2)
+    c, r, im = adversarial.optimize_shadow_position(net, img, m, label, dev(), iterations=2)
+    assert torch.equal(c, c_ref) and abs(float(r) - float(r_ref)) < 1e-6
+    assert (im.cpu() - im_ref).abs().max().item() <= 4 * 0.01 + 1e-6
+    # two compounded 20-step sign attacks: near-zero gradient components drift apart, the bound above still holds
+    assert ((im.cpu() - im_ref).abs() < 1e-6).float().mean().item() > 0.9

@@ -58,9 +58,12 @@ def test_apply_shadow_closed_form(k):
     assert torch.equal(got3, got)
 
 
-def test_apply_shadow_rejects_classifier():
-    with pytest.raises(NotImplementedError):
-        shadow.apply_shadow(torch.zeros(3, 8, 8), (1, 1), 2.0, torch.ones(1, 8, 8), classifier=object())
+def test_apply_shadow_rejects_a_classifier_without_a_hip_backward():
+    """No autograd fallback: only a victim with a HIP backward plan can drive the gradient attack."""
+    from advshadow_amd import AdvsError
+    with pytest.raises(AdvsError, match="no HIP backward plan"):
+        shadow.apply_shadow(torch.zeros(3, 16, 16), (1, 1), 2.0, torch.ones(1, 16, 16), classifier=object(),
+                            target_label=torch.tensor([0]))
 
 
 @pytest.mark.parametrize("shape", [(256, 256, 224), (64, 64, 224), (375, 500, 224), (256, 256, 64), (33, 77, 64)])
