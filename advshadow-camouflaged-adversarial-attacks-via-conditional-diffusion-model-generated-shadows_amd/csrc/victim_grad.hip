@@ -211,7 +211,10 @@ conv_stem_bwd_kernel(const T* __restrict__ g, const float* __restrict__ w, float
     const long long npix = (long long)B * H * W;
     for (long long pix = (long long)blockIdx.x * 256 + threadIdx.x; pix < npix; pix += (long long)gridDim.x * 256) {
         const int b = (int)(pix / ((long long)H * W)), rem = (int)(pix - (long long)b * H * W);
-        const int iy = rem / W, ix = rem - iy * W;
+        // which taps exist depends on the pixel's parity (for stride 2): walk a row's even columns first, then its odd
+        // ones, so that the lanes of a wave mostly share the tap set instead of masking each other out
+        const int iy = rem / W, j = rem - iy * W, he = (W + 1) >> 1;
+        const int ix = j < he ? 2 * j : 2 * (j - he) + 1;
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         for (int r = 0; r < K; ++r) {
             const int ty = iy + pad - r;
