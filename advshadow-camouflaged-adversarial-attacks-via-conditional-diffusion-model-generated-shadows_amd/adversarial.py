@@ -121,9 +121,10 @@ def integrated_gradient_perturbation(classifier, original_image, label, device, 
 
 
 def apply_shadow_adversarial_batch(model, images, centers, radii, feature_masks, labels, shadow_intensity=0.43,
-                                   epsilon=0.01, blur_kernel_size=5, alpha=0.005, iterations=20):
+                                   epsilon=0.01, blur_kernel_size=5, alpha=0.005, iterations=20, integrated=None):
     """Batched classifier branch of ``apply_shadow`` (train_shadow.py:242-266): shadow composite, gradient attack on the
-    shadowed image restricted to the combined mask, blend back through that mask, clamp."""
+    shadowed image restricted to the combined mask, blend back through that mask, clamp.
+    ``integrated`` = dict(steps=, iterations=, baseline=) switches the attack to ddim2/test.py:647-681 (one image)."""
     lib = _lib.load()
     B, Cc, H, W = images.shape
     dev = images.device
@@ -138,35 +139,62 @@ def apply_shadow_adversarial_batch(model, images, centers, radii, feature_masks,
     check(lib.advs_apply_shadow_parts(img.data_ptr(), fm.data_ptr(), ctr.data_ptr(), rad.data_ptr(), shadowed.data_ptr(),
                                       cm.data_ptr(), B, Cc, H, W, fm.shape[1], float(shadow_intensity), arr, len(taps), s),
           "apply_shadow_parts")
-    adv, _ = adversarial_perturbation_batch(model, shadowed, labels, cm, epsilon, alpha, iterations)
+    if integrated is None:
+        adv, _ = adversarial_perturbation_batch(model, shadowed, labels, cm, epsilon, alpha, iterations)
+    else:
+        if B != 1:
+            raise ValueError("the integrated-gradient attack takes one image at a time (its batch is the interpolation path)")
+        one, _ = integrated_gradient_perturbation(model, shadowed[0], labels, dev, cm[0], epsilon, alpha,
+                                                  integrated.get("iterations", 10), integrated.get("steps", 20),
+                                                  integrated.get("baseline"))
+        adv = one[None].contiguous()
     check(lib.advs_blend_mask_clamp01(img.data_ptr(), adv.data_ptr(), cm.data_ptr(), out.data_ptr(), img.numel(), s),
           "blend_mask_clamp01")
     return out
 
 
-def optimize_shadow_position(classifier, original_image, mask, target_label, device, lr=1e-1, iterations=1):
+def optimize_shadow_position(classifier, original_image, mask, target_label, device, lr=1e-1, iterations=1,
+                             variant="train_shadow", baselines=None, ig_iterations=10, ig_steps=20):
     """Reference signature (tools/train_shadow.py:76-77).  Returns (shadow_center, shadow_radius, shadowed_image).
 
     What the reference's loop computes: the shadow centre stays at the mask's centroid -- taken as ``mean(0)[1:]`` of
     ``nonzero(mask)``, i.e. (row, column), and then used by ``apply_shadow`` as (x, y); kept as is.  The only
     differentiable path from the loss to ``shadow_radius`` is the regulariser ``0.01 * radius**2`` (the circular mask is
     a comparison, the perturbation is detached), so Adam moves the radius by that gradient alone; each iteration applies
-    ``apply_shadow`` (composite + gradient attack) to the previous iteration's image."""
-    from .shadow import apply_shadow
+    ``apply_shadow`` (composite + gradient attack) to the previous iteration's image.
+
+    ``variant="ddim2"`` is ddim2/test.py:479-617 (call it with ``iterations=11`` for that file's default): radius starts at
+    15, AdamW, the regulariser enters the loss with a minus sign (the radius grows), shadow intensity 0.051 and the
+    integrated-gradient attack (``baselines``: optional list of per-iteration [C,H,W] baselines instead of ``torch.randn``;
+    ``ig_iterations`` / ``ig_steps``: that attack's loop counts, the reference's defaults);
+    the Grad-CAM / matplotlib display of that file is not reproduced."""
     dev = torch.device(device) if device is not None else original_image.device
+    model = _victim(classifier)
+    ddim2 = variant == "ddim2"
+    if variant not in ("train_shadow", "ddim2"):
+        raise ValueError(f"optimize_shadow_position: unknown variant {variant!r}")
     mask = torch.as_tensor(mask)
     idx = torch.nonzero(mask.cpu())
     mask_center = idx.float().mean(0)[1:]
     shadow_center = mask_center.clone()
-    radius = torch.nn.Parameter(torch.tensor(20.0))
-    opt = torch.optim.Adam([radius], lr=lr)                        # host scalar: the reference's optimiser itself
+    radius = torch.nn.Parameter(torch.tensor(15.0 if ddim2 else 20.0))
+    # host scalar: the reference's optimiser itself
+    opt = torch.optim.AdamW([radius], lr=lr) if ddim2 else torch.optim.Adam([radius], lr=lr)
     image = original_image.clone().to(dev)
-    H, W = original_image.shape[1], original_image.shape[2]
-    for _ in range(int(iterations)):
+    Cc, H, W = original_image.shape
+    fm = _mask4(mask, 1, Cc, H, W, dev)
+    label = torch.as_tensor(target_label).reshape(1)
+    for it in range(int(iterations)):
         opt.zero_grad()
-        image = apply_shadow(image, shadow_center, float(radius.detach()), mask, classifier=classifier,
-                             target_label=target_label, device=dev)
-        radius.grad = (0.01 * 2.0 * radius.detach()).clone()       # d (-adv + 0.01 * (|c - c0|^2 + r^2)) / d r
+        ctr = torch.as_tensor([float(shadow_center[0]), float(shadow_center[1])])[None]
+        rad = torch.as_tensor([float(radius.detach())])
+        if ddim2:
+            integ = {"iterations": ig_iterations, "steps": ig_steps, "baseline": None if baselines is None else baselines[it]}
+            image = apply_shadow_adversarial_batch(model, image[None], ctr, rad, fm, label, 0.051, 0.01, 5, integrated=integ)[0]
+        else:
+            image = apply_shadow_adversarial_batch(model, image[None], ctr, rad, fm, label)[0]
+        # d loss / d r: loss = -adv + 0.01 * (|c - c0|^2 + r^2)  |  ddim2: -100 * adv - 0.01 * (...)
+        radius.grad = ((-0.02 if ddim2 else 0.02) * radius.detach()).clone()
         opt.step()
         with torch.no_grad():
             shadow_center.clamp_(min=0, max=W)

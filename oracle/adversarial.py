@@ -89,3 +89,43 @@ def optimize_shadow_position(sd, original_image, mask, target_label, lr=1e-1, it
             radius.clamp_(min=0, max=min(original_image.size(1), original_image.size(2)) / 2)
         image = upd.detach()
     return shadow_center.detach(), radius.detach(), image
+
+
+def apply_shadow_ig(sd, image, shadow_center, shadow_radius, feature_mask, target_label, baseline, shadow_intensity=0.051,
+                    epsilon=0.01, blur_kernel_size=5, ig_iterations=10, ig_steps=20):
+    """ddim2/test.py:830-871: as apply_shadow, with the integrated-gradient attack (epsilon 0.01, defaults otherwise)."""
+    C, H, W = image.shape
+    Y, X = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    dist = torch.sqrt((X - shadow_center[0]) ** 2 + (Y - shadow_center[1]) ** 2)
+    m = (dist <= shadow_radius).float()
+    mb = torch.from_numpy(gaussian_blur_reflect101(m.numpy(), blur_kernel_size))
+    cm = mb * feature_mask
+    shadowed = image * (1 - cm) + cm * (image * (1 - shadow_intensity))
+    adv, _, _ = integrated_gradient_perturbation(sd, shadowed, target_label, cm, baseline, epsilon, 0.005, ig_iterations, ig_steps)
+    return torch.clamp(image * (1 - cm) + adv * cm, 0, 1)
+
+
+def optimize_shadow_position_ddim2(sd, original_image, mask, target_label, baselines, lr=1e-1, iterations=11,
+                                   ig_iterations=10, ig_steps=20):
+    """ddim2/test.py:479-617 without its Grad-CAM / matplotlib display: AdamW, radius from 15, loss = -100 adv - 0.01 reg."""
+    mask_center = torch.nonzero(mask).float().mean(0)[1:]
+    shadow_center = mask_center.clone()
+    radius = torch.nn.Parameter(torch.tensor(15.0), requires_grad=True)
+    opt = torch.optim.AdamW([radius], lr=lr)
+    image = original_image.clone()
+    for it in range(iterations):
+        opt.zero_grad()
+        upd = apply_shadow_ig(sd, image, shadow_center, radius, mask, target_label, baselines[it],
+                              ig_iterations=ig_iterations, ig_steps=ig_steps)
+        out = resnet50_logits(sd, upd[None])
+        adv_loss = F.cross_entropy(out, target_label)
+        reg = (shadow_center - mask_center).pow(2).sum() + radius.pow(2)
+        loss = -100 * adv_loss - reg * 0.01
+        loss.backward()
+        if radius.grad is not None:
+            opt.step()
+        with torch.no_grad():
+            shadow_center.clamp_(min=0, max=original_image.size(2))
+            radius.clamp_(min=0, max=min(original_image.size(1), original_image.size(2)) / 2)
+        image = upd.detach()
+    return shadow_center.detach(), radius.detach(), image

@@ -201,3 +201,19 @@ def test_apply_shadow_with_classifier_and_position_search():
     assert (im.cpu() - im_ref).abs().max().item() <= 4 * 0.01 + 1e-6
     # two compounded 20-step sign attacks: near-zero gradient components drift apart, the bound above still holds
     assert ((im.cpu() - im_ref).abs() < 1e-6).float().mean().item() > 0.9
+
+
+def test_position_search_ddim2_variant():
+    """ddim2/test.py:479-617 (AdamW, growing radius, integrated-gradient attack) with the baselines passed in."""
+    net, sd = make_victim(seed=8)
+    g = torch.Generator().manual_seed(15)
+    img = torch.rand(3, 64, 64, generator=g)
+    label, m = torch.tensor([4]), _mask(64, 4)
+    bases = [torch.randn(3, 64, 64, generator=g) for _ in range(2)]
+    # the oracle's attack loops ig_iterations x (ig_steps + 1) backward passes per iteration on the CPU: keep it short
+    c_ref, r_ref, im_ref = oa.optimize_shadow_position_ddim2(sd, img, m, label, bases, iterations=2, ig_iterations=3, ig_steps=4)
+    c, r, im = adversarial.optimize_shadow_position(net, img, m, label, dev(), iterations=2, variant="ddim2", baselines=bases,
+                                                    ig_iterations=3, ig_steps=4)
+    assert torch.equal(c, c_ref) and abs(float(r) - float(r_ref)) < 1e-6 and float(r) > 15.0
+    assert (im.cpu() - im_ref).abs().max().item() <= 4 * 0.01 + 1e-6
+    assert ((im.cpu() - im_ref).abs() < 1e-6).float().mean().item() > 0.9
