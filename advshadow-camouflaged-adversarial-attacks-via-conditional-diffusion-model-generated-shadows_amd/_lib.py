@@ -22,7 +22,7 @@ class ConvArgs(C.Structure):
                 ("b", i32), ("h", i32), ("w_", i32), ("c1", i32), ("c2", i32), ("cout", i32),
                 ("ksize", i32), ("stride", i32), ("pad", i32), ("upsample", i32),
                 ("act", i32), ("dtype", i32), ("temb_stride", i32), ("tile", i32), ("stats", vp), ("stats_rows", i32), ("e1", vp), ("e2", vp), ("ce1", i32), ("ce2", i32),
-                ("ld1", i32), ("ld2", i32)]
+                ("ld1", i32), ("ld2", i32), ("relu_mask", vp)]
 
 
 # name -> argtypes (restype is int unless listed in _RESTYPES)

@@ -21,6 +21,7 @@ struct ConvKP {
     const char* e1; const char* e2;   // extra 1x1 operand (two concat sources) appended to K, or null
     int E1, E2; unsigned e1_bytes, e2_bytes;
     const float* bias; const float* temb; const char* res; char* y;
+    const char* mask;            // ReLU-backward mask (advs_conv_args.relu_mask), read only by the MASK instantiations
     float* stats;                // [ceil(M/WM)][Cout][2] per-channel (sum, sum of squares) of y, or null
     unsigned x1_bytes, x2_bytes, w_bytes;
     int B, H, W, C1, C2, Cout;
@@ -69,7 +70,7 @@ template <> struct Mma<float> {
 //   row_to_m(lr): output pixel index of the wave's local row lr (0 .. TM*32), or -1 when out of range
 //   temb_b: batch index when every row of the wave shares it (temb folded into the bias), -1 = per row
 //   rb: row-block index for the epilogue statistics, -1 = this wave writes none
-template <typename T, int WN, int TM, int TN, typename RowMap>
+template <typename T, int WN, int TM, int TN, bool MASK = false, typename RowMap>
 __device__ __forceinline__ void conv_epilogue(const ConvKP& p, f32x16 (&acc)[TM][TN], float* patch, int lane,
                                               int ncol0, RowMap row_to_m, int temb_b, int rb) {
     constexpr int VEC = 16 / Mma<T>::ESZ;
@@ -96,7 +97,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvKP& p, f32x16 (&acc)[TM]
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         // this strip's residual vectors are requested first so their latency overlaps the LDS transpose
-        u32x4 rraw[NIT];
+        u32x4 rraw[NIT], mraw[MASK ? NIT : 1];
+        if (MASK) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int m = row_to_m(i * 32 + it * RPI + prow);
+                mraw[it] = (m >= 0 && n_ok) ? *(const u32x4*)((const T*)p.mask + (size_t)m * p.Cout + n) : u32x4{0, 0, 0, 0};
+            }
+        }
         if (res) {
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
@@ -144,6 +152,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvKP& p, f32x16 (&acc)[TM]
                 if (res && res_after) {                  // y = act(conv) + x (FusedMBConv with expand 1: Conv-BN-SiLU, then add)
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) v[e] += rv[e];
+                }
+                if (MASK) {                              // ReLU backward: gradient only where the forward activation was positive
+                    float mv[VEC];
+                    unpack16<T>(mraw[it], mv);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) v[e] = mv[e] > 0.f ? v[e] : 0.f;
                 }
                 const u32x4 packed = pack16<T>(v);
                 *(u32x4*)(y + o) = packed;

@@ -30,7 +30,7 @@
 #include "conv_common.h"
 #include <stdlib.h>
 
-template <typename T, int BM, int BN, int WM, int WN, int NSTAGE, bool ILV>
+template <typename T, int BM, int BN, int WM, int WN, int NSTAGE, bool ILV, bool MASK = false>
 __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
 conv_igemm_kernel(const ConvKP p) {
     constexpr int ESZ = Mma<T>::ESZ;
@@ -289,23 +289,23 @@ conv_igemm_kernel(const ConvKP p) {
     const int mw = m0 + wr * WM;                               // first row of this wave
     const bool wave_live = mw < p.M;
     const int temb_b = (p.temb && HoWo % WM == 0 && wave_live) ? (int)p.dHoWo.div((unsigned)mw) : -1;
-    conv_epilogue<T, WN, TM, TN>(p, acc, (float*)smem + wave * (32 * WN), lane, n0 + wc * WN,
+    conv_epilogue<T, WN, TM, TN, MASK>(p, acc, (float*)smem + wave * (32 * WN), lane, n0 + wc * WN,
                                  [&](int lr) { const int m = mw + lr; return m < p.M ? m : -1; },
                                  temb_b, wave_live ? mw / WM : -1);
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int NSTAGE = 2, bool ILV = false>
+template <typename T, int BM, int BN, int WM, int WN, int NSTAGE = 2, bool ILV = false, bool MASK = false>
 static int conv_launch(ConvKP& p, hipStream_t st) {
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
     constexpr int lds = NSTAGE * (BM + BN) * SLAB;
     static bool attr_set = false;
     if (!attr_set) {
-        ADVS_HIP(hipFuncSetAttribute((const void*)conv_igemm_kernel<T, BM, BN, WM, WN, NSTAGE, ILV>,
+        ADVS_HIP(hipFuncSetAttribute((const void*)conv_igemm_kernel<T, BM, BN, WM, WN, NSTAGE, ILV, MASK>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
     p.nMt = cdiv(p.M, BM); p.nNt = cdiv(p.Cout, BN);
-    conv_igemm_kernel<T, BM, BN, WM, WN, NSTAGE, ILV><<<p.nMt * p.nNt, NT, lds, st>>>(p);
+    conv_igemm_kernel<T, BM, BN, WM, WN, NSTAGE, ILV, MASK><<<p.nMt * p.nNt, NT, lds, st>>>(p);
     ADVS_CHECK_LAUNCH("conv_igemm");
     return ADVS_OK;
 }
@@ -320,6 +320,10 @@ int conv_halo_extra_dispatch(ConvKP& p, int dtype, hipStream_t st);
 template <typename T>
 static int conv_dispatch(ConvKP& p, int tile, hipStream_t st) {
     if (tile == 0) tile = pick_tile((long long)p.Ho * p.Wo, p.Cout);
+    if (p.mask) {                       // ReLU-backward epilogue: its own instantiations, the others never read p.mask
+        if (tile == 4) return conv_launch<T, 256, 256, 128, 64, 2, true, true>(p, st);
+        return conv_launch<T, 128, 128, 64, 64, 2, false, true>(p, st);
+    }
     switch (tile) {
         // ILV (DMA issue spread between the MFMA groups) pays when both waves of a SIMD belong to one
         // workgroup and so run in lockstep (8-wave tiles); with two 4-wave workgroups per CU the plain
@@ -353,6 +357,7 @@ static int pick_tile(long long m_img, int cout) {
 // multiple of 16: +15..30 % over the per-tap tiles on every such layer of the eps-predictor, tools/tune_conv.py)
 static int resolve_tile(const advs_conv_args* a, long long m_img) {
     if (a->upsample == ADVS_UPSAMPLE_SUBPIXEL) return 12;       // weights are packed per output parity: one kernel only
+    if (a->relu_mask) return a->tile ? a->tile : pick_tile(m_img, a->cout);
     if (g_tile_override) return g_tile_override;
     if (a->tile) return a->tile;
     // (with a fused 1x1 operand tile 10 becomes 13: the same kernel with one-tap units behind the 3x3 slabs, +3 %)
@@ -393,6 +398,9 @@ extern "C" int advs_conv2d(const advs_conv_args* a, void* stream) {
     p.x1 = (const char*)a->x1; p.x2 = (const char*)a->x2; p.w = (const char*)a->w;
     p.bias = a->bias; p.temb = a->temb; p.res = (const char*)a->residual; p.y = (char*)a->y;
     p.stats = a->stats;
+    p.mask = (const char*)a->relu_mask;
+    ADVS_REQUIRE(!a->relu_mask || (!a->stats && a->upsample != ADVS_UPSAMPLE_SUBPIXEL && (a->tile == 0 || a->tile == 1 || a->tile == 4)),
+                 "conv2d: relu_mask needs a per-tap tile (0, 1 or 4), no stats, no sub-pixel upsample");
     p.B = a->b; p.H = a->h; p.W = a->w_; p.C1 = a->c1; p.C2 = a->c2; p.Cout = a->cout;
     p.LD1 = a->ld1 > 0 ? a->ld1 : a->c1; p.LD2 = a->ld2 > 0 ? a->ld2 : a->c2;
     ADVS_REQUIRE(p.LD1 <= a->c1 && p.LD2 <= a->c2 && (p.LD1 * esz) % 16 == 0 && (p.LD2 * esz) % 16 == 0 && a->ld1 >= 0 && a->ld2 >= 0,

@@ -143,8 +143,9 @@ class Builder:
     # ---- ops (activations are NHWC tensors [B,H,W,C] of the compute dtype)
     def conv(self, x1, w, cout, *, x2=None, bias=None, temb=None, temb_stride=0, residual=None,
              ksize=3, stride=1, pad=1, upsample=False, act=None, out=None, tile=0, want_stats=False, extra=None,
-             residual_after_act=False):
-        """extra = (e1, e2_or_None): NHWC tensors at the OUTPUT resolution whose 1x1 conv is summed in;
+             residual_after_act=False, relu_mask=None):
+        """relu_mask: forward activation whose ReLU backward is fused into this (data-gradient) conv.
+        extra = (e1, e2_or_None): NHWC tensors at the OUTPUT resolution whose 1x1 conv is summed in;
         ``w`` then holds [taps * (C1 + C2) | E1 + E2] per output channel."""
         B, H, W, L1 = x1.shape
         L2 = 0 if x2 is None else x2.shape[3]
@@ -162,7 +163,7 @@ class Builder:
                      ACT[act] | (GN_RESIDUAL_AFTER_ACT if residual_after_act else 0), self.dt, temb_stride, tile, 0, 0,
                      ptr(extra[0]) if extra else 0, ptr(extra[1]) if extra and extra[1] is not None else 0,
                      extra[0].shape[3] if extra else 0, extra[1].shape[3] if extra and extra[1] is not None else 0,
-                     L1 if L1 != C1 else 0, L2 if L2 != C2 else 0)
+                     L1 if L1 != C1 else 0, L2 if L2 != C2 else 0, ptr(relu_mask))
         kw = 16 * (C1 + C2) if subpixel else ksize * ksize * (C1 + C2) + a.ce1 + a.ce2
         if w.numel() != cout * kw:
             raise ValueError(f"conv: packed weight has {w.numel()} elements, expected {cout} x {kw} "
@@ -176,7 +177,7 @@ class Builder:
                 stats = self.buf((B * Ho * Wo // rows, cout, 2), torch.float32)
                 self.stats[y.data_ptr()] = (stats, Ho * Wo // rows)
                 a.stats, a.stats_rows = ptr(stats), rows
-        self.plan.add(self.lib.advs_conv2d, C.byref(a), keep=(a, x1, x2, w, bias, temb, residual, y, stats, extra))
+        self.plan.add(self.lib.advs_conv2d, C.byref(a), keep=(a, x1, x2, w, bias, temb, residual, y, stats, extra, relu_mask))
         return y
 
     def conv_first(self, x_nchw, w, bias, cout, want_stats=False):

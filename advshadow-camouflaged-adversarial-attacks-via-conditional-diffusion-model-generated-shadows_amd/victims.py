@@ -206,7 +206,8 @@ class _ResNetGradEngine:
 
     Backward of one bottleneck, with G = d loss / d (pre-ReLU block output), already masked by the block's ReLU:
       g2 = conv1x1(G, w3^T) * [y2 > 0];  g1 = conv3x3(zero_insert(g2), flip(w2)^T) * [y1 > 0];
-      d h = conv1x1(g1, w1^T) + (downsample ? zero_insert(conv1x1(G, wd^T)) : G);  next G = d h * [h > 0].
+      d h = conv1x1(g1, w1^T) + (downsample ? zero_insert(conv1x1(G, wd^T)) : G);  next G = d h * [h > 0]
+    (each mask is the ``relu_mask`` operand of the conv that produces the masked tensor).
     BatchNorm is folded into the conv weights exactly as in the forward, so its backward is the folded conv's."""
 
     def __init__(self, model, W, G, batch, size, dt):
@@ -249,9 +250,6 @@ class _ResNetGradEngine:
             g = bld.buf(tuple(h.shape))
             plan.add(lib.advs_avgpool_bwd_relu, ptr(gp), ptr(h), ptr(g), batch, hh * ww, cc, dt, keep=(gp, h, g))
 
-            def relu_bwd(t, y):
-                plan.add(lib.advs_relu_bwd, ptr(t), 0, ptr(y), ptr(t), t.numel(), dt, keep=(t, y))
-
             def zero_insert(t, like):
                 z = bld.buf((batch, like.shape[1], like.shape[2], t.shape[3]))
                 plan.add(lib.advs_zero_insert2x, ptr(t), ptr(z), batch, t.shape[1], t.shape[2], t.shape[3], like.shape[1],
@@ -259,13 +257,12 @@ class _ResNetGradEngine:
                 bld.free(t)
                 return z
 
+            # the ReLU masks ride the conv epilogues (advs_conv_args.relu_mask) except behind a zero insertion
             for (p, cin, width, cout, s, ds), (hin, y1, y2, y3) in zip(reversed(model.blocks), reversed(acts)):
-                g2 = bld.conv(g, G[p + ".w3T"], width, ksize=1, pad=0)
-                relu_bwd(g2, y2)
+                g2 = bld.conv(g, G[p + ".w3T"], width, ksize=1, pad=0, relu_mask=y2)
                 if s == 2:
                     g2 = zero_insert(g2, y1)
-                g1 = bld.conv(g2, G[p + ".w2T"], width, ksize=3, stride=1, pad=1)
-                relu_bwd(g1, y1)
+                g1 = bld.conv(g2, G[p + ".w2T"], width, ksize=3, stride=1, pad=1, relu_mask=y1)
                 bld.free(g2)
                 if ds:
                     res = bld.conv(g, G[p + ".wdT"], cin, ksize=1, pad=0)
@@ -274,11 +271,11 @@ class _ResNetGradEngine:
                     bld.free(g)
                 else:
                     res = g
-                gh = bld.conv(g1, G[p + ".w1T"], cin, residual=res, ksize=1, pad=0)
+                # the first block reads the max-pooled stem: its ReLU is applied by advs_maxpool3x3s2_bwd_relu below
+                gh = bld.conv(g1, G[p + ".w1T"], cin, residual=res, ksize=1, pad=0,
+                              relu_mask=None if hin is acts[0][0] else hin)
                 bld.free(g1)
                 bld.free(res)
-                if hin is not acts[0][0]:                      # the first block reads the max-pooled stem: its ReLU is
-                    relu_bwd(gh, hin)                          # applied by advs_maxpool3x3s2_bwd_relu below
                 for t in (y1, y2, y3):
                     bld.free(t)
                 g = gh

@@ -88,6 +88,10 @@ typedef struct advs_conv_args {
                                            the weights of channels [ld, c) must be zero (they meet the next pixel's
                                            data, or zeros past the end of the buffer) -- 32-channel bf16 layers of
                                            CSPDarkUnet (model/networks/cspdarkunet.py:24-29)                        */
+    const void* relu_mask;              /* NULL, or NHWC [b][ho][wo][cout]: y is zeroed wherever relu_mask <= 0, after bias /
+                                           residual / act -- ReLU backward fused into a data-gradient conv (the mask is the
+                                           forward activation behind the ReLU; train_shadow.py:209 loss.backward()).
+                                           Per-tap tiles only (tile 0 | 1 | 4), no stats.                                */
 } advs_conv_args;
 int advs_conv2d(const advs_conv_args* a, void* stream);
 int advs_conv_set_tile(int tile);       /* tuning hook: non-zero overrides every call's tile  */

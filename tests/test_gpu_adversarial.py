@@ -92,6 +92,26 @@ def test_zero_insert_and_relu_backward(dt):
     assert (nchw(out) - refb).abs().max().item() < (1e-6 if dt == "fp32" else 4e-2)
 
 
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", [(2, 14, 14, 256, 64, 1, 0), (1, 16, 16, 64, 64, 3, 0), (2, 7, 9, 512, 256, 1, 4), (1, 28, 28, 64, 256, 1, 1)])
+def test_conv_relu_mask_epilogue(case, dt):
+    """advs_conv_args.relu_mask: y = [mask > 0] * (conv + residual), on the 128x128 and 256x256 per-tap tiles."""
+    from advshadow_amd.engine import pack_conv_weight, dtype_code
+    B, H, W, Cin, Cout, k, tile = case
+    g = torch.Generator().manual_seed(Cin + Cout)
+    r = (lambda t: t.bfloat16().float()) if dt == "bf16" else (lambda t: t)
+    x, res, mask = (r(torch.randn(B, c, H, W, generator=g)) for c in (Cin, Cout, Cout))
+    w = r(torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5)
+    ref = torch.where(mask > 0, F.conv2d(x, w, padding=k // 2) + res, torch.zeros(()))
+    op = OneOp(dt, B)
+    y = op.b.conv(nhwc(x, dt), pack_conv_weight(w.to(dev()), dtype_code(dt)), Cout, residual=nhwc(res, dt), ksize=k, pad=k // 2,
+                  relu_mask=nhwc(mask, dt), tile=tile)
+    op.go()
+    got = nchw(y)
+    assert torch.equal(got == 0, ref == 0) or ((got == 0) == (mask <= 0)).all()
+    assert (got - ref).abs().max().item() < (2e-5 if dt == "fp32" else 5e-2)
+
+
 @pytest.mark.parametrize("size,batch", [(64, 2), (72, 1)])
 def test_input_gradient_fp32_matches_autograd(size, batch):
     """Whole network: 72 exercises the odd stride-2 pre-images (9 -> 5 -> 3)."""
