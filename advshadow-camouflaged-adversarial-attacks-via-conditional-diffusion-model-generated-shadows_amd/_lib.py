@@ -78,6 +78,8 @@ SIGNATURES = {
     "advs_jpeg_roundtrip_u8": [vp, vp, vp, i32, i32, i32, i32, vp],
     "advs_argmax_rows": [vp, vp, i32, i32, vp],
     "advs_conv_stem": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "advs_im2col_nchw": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "advs_col2im_nchw": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "advs_maxpool3x3s2": [vp, vp, i32, i32, i32, i32, i32, vp],
     "advs_global_avgpool": [vp, vp, i32, i32, i32, i32, vp],
     "advs_softmax_ce_grad": [vp, vp, vp, i32, i32, f32, vp],

@@ -71,6 +71,51 @@ extern "C" int advs_conv_stem(const float* x_nchw, const float* w_oihw, const fl
     return ADVS_OK;
 }
 
+// ---------------------------------------------------------------- stem as a GEMM: im2col of the NCHW f32 image
+// y[b][oy][ox][k] = x[b][c][oy*stride + r - pad][ox*stride + s - pad] (0 outside), k = (c*K + r)*K + s < Cin*K*K, zero for
+// the padding columns k in [Cin*K*K, Kp).  The stem conv is then advs_conv2d 1x1 over Kp channels with the OIHW weight
+// viewed as [cout][Cin*K*K] (zero-padded to Kp): the 7x7 stride-2 conv of ResNet-50 (K = 147) moves from the VALU kernel
+// above onto MFMA.  One 16-byte vector of consecutive k per lane.
+template <typename T>
+__global__ void im2col_nchw_kernel(const float* __restrict__ x, u32x4* __restrict__ y, int B, int Cin, int H, int W, int K,
+                                   int stride, int pad, int Ho, int Wo, int Kp) {
+    constexpr int VEC = Elt<T>::VEC;
+    const int vpp = Kp / VEC, KK = Cin * K * K;
+    const size_t total = (size_t)B * Ho * Wo * vpp;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int kv = (int)(i % vpp);
+        size_t rr = i / vpp;
+        const int ox = (int)(rr % Wo); rr /= Wo;
+        const int oy = (int)(rr % Ho);
+        const int b = (int)(rr / Ho);
+        float v[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const int k = kv * VEC + j;
+            const int c = k / (K * K), rs = k - c * K * K, r = rs / K, s = rs - r * K;
+            const int iy = oy * stride + r - pad, ix = ox * stride + s - pad;
+            v[j] = (k < KK && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                       ? x[(((size_t)b * Cin + c) * H + iy) * W + ix] : 0.f;
+        }
+        y[i] = pack16<T>(v);
+    }
+}
+
+extern "C" int advs_im2col_nchw(const float* x_nchw, void* y, int b, int cin, int h, int w, int ksize, int stride, int pad,
+                                int kp, int dtype, void* stream) {
+    ADVS_REQUIRE(dtype_ok(dtype), "advs_im2col_nchw: unknown dtype code %d", dtype);
+    const int vec = dtype == ADVS_F32 ? 4 : 8;
+    ADVS_REQUIRE(x_nchw && y && b > 0 && cin > 0 && h > 0 && w > 0 && ksize >= 1 && stride >= 1 && pad >= 0, "im2col_nchw: bad args");
+    ADVS_REQUIRE(kp >= cin * ksize * ksize && kp % vec == 0, "im2col_nchw: kp=%d must be >= %d and a multiple of %d", kp, cin * ksize * ksize, vec);
+    const int ho = (h + 2 * pad - ksize) / stride + 1, wo = (w + 2 * pad - ksize) / stride + 1;
+    ADVS_REQUIRE(ho > 0 && wo > 0, "im2col_nchw: empty output");
+    const size_t total = (size_t)b * ho * wo * (kp / vec);
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    ADVS_SWITCH_T(dtype, im2col_nchw_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>(x_nchw, (u32x4*)y, b, cin, h, w, ksize, stride, pad, ho, wo, kp));
+    ADVS_CHECK_LAUNCH("im2col_nchw");
+    return ADVS_OK;
+}
+
 // ---------------------------------------------------------------- MaxPool2d(3, stride 2, pad 1), NHWC
 template <typename T>
 __global__ void maxpool3s2_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, int Ho, int Wo) {

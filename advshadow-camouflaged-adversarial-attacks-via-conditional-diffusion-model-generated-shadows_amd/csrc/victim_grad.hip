@@ -262,6 +262,86 @@ extern "C" int advs_conv_stem_bwd(const void* g, const float* w_oihw, float* dx_
     return ADVS_OK;
 }
 
+// ---------------------------------------------------------------- col2im: the adjoint of advs_im2col_nchw
+// dx[b][c][iy][ix] = sum over the (oy, r), (ox, s) with oy*stride + r - pad = iy, ox*stride + s - pad = ix of
+// gcol[b][oy][ox][(c*K + r)*K + s];  gcol = advs_conv2d 1x1 of the stem-output gradient with the [Kp][cout] transposed
+// stem weight.  Gather form, deterministic.  A workgroup owns a 16x16 tile of image pixels: the column rows that reach
+// it (<= ((16 + K - 2) / stride + 1)^2 of them) are copied into LDS with coalesced reads, then every lane sums its taps
+// from LDS.  Wave w takes the pixels of parity class (w >> 1, w & 1), so for stride 2 a wave shares one tap set.
+constexpr int C2I_T = 16;
+template <typename T>
+__global__ void __launch_bounds__(256)
+col2im_nchw_kernel(const T* __restrict__ gcol, float* __restrict__ dx, int Cin, int H, int W, int K,
+                   int stride, int pad, int Ho, int Wo, int Kp, int tiles_x, int tiles_y) {
+    extern __shared__ __align__(16) unsigned char c2i_smem[];
+    T* cols = (T*)c2i_smem;
+    const int KK = Cin * K * K;
+    int blk = blockIdx.x;
+    const int tx = blk % tiles_x; blk /= tiles_x;
+    const int ty = blk % tiles_y;
+    const int b = blk / tiles_y;
+    const int iy0 = ty * C2I_T, ix0 = tx * C2I_T;
+    // output rows / columns whose window touches the tile
+    const int lo_y = iy0 + pad - (K - 1), lo_x = ix0 + pad - (K - 1);
+    const int oy_lo = lo_y > 0 ? (lo_y + stride - 1) / stride : 0, ox_lo = lo_x > 0 ? (lo_x + stride - 1) / stride : 0;
+    int oy_hi = (iy0 + C2I_T - 1 + pad) / stride, ox_hi = (ix0 + C2I_T - 1 + pad) / stride;
+    oy_hi = oy_hi < Ho - 1 ? oy_hi : Ho - 1; ox_hi = ox_hi < Wo - 1 ? ox_hi : Wo - 1;
+    const int nOy = oy_hi - oy_lo + 1, nOx = ox_hi - ox_lo + 1;
+    if (nOy > 0 && nOx > 0) {
+        const int total = nOy * nOx * KK;
+        for (int i = threadIdx.x; i < total; i += 256) {
+            const int e = i % KK, row = i / KK;
+            const int oy = oy_lo + row / nOx, ox = ox_lo + row % nOx;
+            cols[i] = gcol[(((size_t)b * Ho + oy) * Wo + ox) * Kp + e];
+        }
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int iy = iy0 + 2 * (lane >> 3) + (wave >> 1), ix = ix0 + 2 * (lane & 7) + (wave & 1);
+    if (iy >= H || ix >= W) return;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < K; ++r) {
+        const int t = iy + pad - r;
+        if (t < 0 || t % stride) continue;
+        const int oy = t / stride;
+        if (oy < oy_lo || oy > oy_hi) continue;
+        for (int s = 0; s < K; ++s) {
+            const int u = ix + pad - s;
+            if (u < 0 || u % stride) continue;
+            const int ox = u / stride;
+            if (ox < ox_lo || ox > ox_hi) continue;
+            const T* gp = cols + ((oy - oy_lo) * nOx + (ox - ox_lo)) * KK + r * K + s;
+            for (int c = 0; c < Cin; ++c) acc[c] += Elt<T>::ld(gp + c * K * K);
+        }
+    }
+    for (int c = 0; c < Cin; ++c) dx[(((size_t)b * Cin + c) * H + iy) * W + ix] = acc[c];
+}
+
+extern "C" int advs_col2im_nchw(const void* gcol, float* dx_nchw, int b, int cin, int h, int w, int ksize, int stride, int pad,
+                                int kp, int dtype, void* stream) {
+    ADVS_REQUIRE(dtype_ok(dtype), "advs_col2im_nchw: unknown dtype code %d", dtype);
+    ADVS_REQUIRE(gcol && dx_nchw && b > 0 && cin >= 1 && cin <= 4 && h > 0 && w > 0 && ksize >= 1 && stride >= 1 && pad >= 0, "col2im_nchw: bad args");
+    ADVS_REQUIRE(kp >= cin * ksize * ksize, "col2im_nchw: kp=%d must be >= %d", kp, cin * ksize * ksize);
+    const int ho = (h + 2 * pad - ksize) / stride + 1, wo = (w + 2 * pad - ksize) / stride + 1;
+    ADVS_REQUIRE(ho > 0 && wo > 0, "col2im_nchw: empty output");
+    const int nmax = (C2I_T + ksize - 2) / stride + 1;
+    const size_t lds = (size_t)nmax * nmax * cin * ksize * ksize * (dtype == ADVS_F32 ? 4 : 2);
+    ADVS_REQUIRE(lds <= 160 * 1024, "col2im_nchw: a tile's %d x %d column rows (%zu bytes) do not fit LDS", nmax, nmax, lds);
+    const int tiles_x = cdiv(w, C2I_T), tiles_y = cdiv(h, C2I_T);
+    const long long blocks = (long long)b * tiles_x * tiles_y;
+    ADVS_REQUIRE(blocks < (1ll << 31), "col2im_nchw: too many tiles");
+    ADVS_SWITCH_T(dtype, {
+        static bool attr_set = false;
+        if (!attr_set) {
+            ADVS_HIP(hipFuncSetAttribute((const void*)col2im_nchw_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+        col2im_nchw_kernel<T><<<(unsigned)blocks, 256, lds, (hipStream_t)stream>>>((const T*)gcol, dx_nchw, cin, h, w, ksize, stride, pad, ho, wo, kp, tiles_x, tiles_y);
+    });
+    ADVS_CHECK_LAUNCH("col2im_nchw");
+    return ADVS_OK;
+}
+
 // ---------------------------------------------------------------- one iterative-gradient update (train_shadow.py:212-216)
 // pert = clamp(pert - alpha * sign(grad * mask), -eps, eps);  x_in = x0 + pert     (all NCHW f32; mask [B][mc][H][W], mc = 1 or C)
 // grad may hold nsum stacked gradients per image ([B][nsum][C][H][W], summed here: the integrated-gradient variant).

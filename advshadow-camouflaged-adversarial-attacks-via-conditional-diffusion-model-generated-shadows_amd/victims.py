@@ -12,7 +12,7 @@ import torch.nn as nn
 
 from . import _lib
 from .diff_model import _attach
-from .engine import Builder, dtype_code, pack_conv_weight, ptr
+from .engine import SLAB_ELEMS, Builder, dtype_code, pack_conv_weight, ptr
 
 _LAYERS = ((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2))     # (width, blocks, stride of first block)
 
@@ -70,6 +70,8 @@ class ResNet50(nn.Module):
         W = {}
         w, b = self._fold(sd, "conv1", "bn1")
         W["stem.w"], W["stem.b"] = w.contiguous(), b
+        # the stem as a GEMM over im2col columns (advs_im2col_nchw): [64][3*7*7 -> padded to whole slabs]
+        W["stem.wg"] = pack_conv_weight(w.reshape(64, 147, 1, 1), dt)
         for p, cin, width, cout, s, ds in self.blocks:
             for i in ("1", "2", "3"):
                 w, b = self._fold(sd, f"{p}.conv{i}", f"{p}.bn{i}")
@@ -109,6 +111,11 @@ class ResNet50(nn.Module):
             if ds:
                 w, _ = self._fold(sd, p + ".downsample.0", p + ".downsample.1")
                 G[p + ".wdT"] = pack_conv_weight(w.permute(1, 0, 2, 3).contiguous(), dt)
+        w, _ = self._fold(sd, "conv1", "bn1")
+        kp = -(-147 // SLAB_ELEMS[dt]) * SLAB_ELEMS[dt]
+        wt = torch.zeros((kp, 64), dtype=torch.float32, device=w.device)
+        wt[:147] = w.reshape(64, 147).t()
+        G["stem.wT"] = pack_conv_weight(wt.reshape(kp, 64, 1, 1), dt)     # column gradients = g_stem @ W, then advs_col2im_nchw
         G["fc.wT"] = sd["fc.weight"].float().t().contiguous()
         self._packed[("grad", dt)] = (ver, G)
         return G
@@ -157,6 +164,16 @@ class ResNet50(nn.Module):
         return out
 
 
+def _resnet_stem(bld, x, W, batch, size, ho, dt):
+    """conv1 + bn1 + ReLU as im2col + a 1x1 conv on the MFMA kernels (the 7x7 stride-2 stem on 3 channels)."""
+    kp = W["stem.wg"].numel() // 64
+    cols = bld.buf((batch, ho, ho, kp))
+    bld.plan.add(bld.lib.advs_im2col_nchw, ptr(x), ptr(cols), batch, 3, size, size, 7, 2, 3, kp, dt, keep=(x, cols))
+    h = bld.conv(cols, W["stem.wg"], 64, bias=W["stem.b"], ksize=1, pad=0, act="relu")
+    bld.free(cols)
+    return h
+
+
 class _ResNetEngine:
     def __init__(self, model, W, batch, size, dt):
         dev = next(model.parameters()).device
@@ -166,9 +183,7 @@ class _ResNetEngine:
             self.x = torch.zeros((batch, 3, size, size), dtype=torch.float32, device=dev)
             lib = bld.lib
             ho = (size + 6 - 7) // 2 + 1
-            h = bld.buf((batch, ho, ho, 64))
-            bld.plan.add(lib.advs_conv_stem, ptr(self.x), ptr(W["stem.w"]), ptr(W["stem.b"]), ptr(h), batch, 3, size, size,
-                         64, 7, 2, 3, _lib.ACT["relu"], dt, keep=(self.x, h))
+            h = _resnet_stem(bld, self.x, W, batch, size, ho, dt)
             hp = (ho + 2 - 3) // 2 + 1
             pooled = bld.buf((batch, hp, hp, 64))
             bld.plan.add(lib.advs_maxpool3x3s2, ptr(h), ptr(pooled), batch, ho, ho, 64, dt, keep=(h, pooled))
@@ -221,9 +236,7 @@ class _ResNetGradEngine:
             self.grad = torch.zeros((batch, 3, size, size), dtype=torch.float32, device=dev)
             # ---- forward (as _ResNetEngine, nothing released)
             ho = (size + 6 - 7) // 2 + 1
-            stem = bld.buf((batch, ho, ho, 64))
-            plan.add(lib.advs_conv_stem, ptr(self.x), ptr(W["stem.w"]), ptr(W["stem.b"]), ptr(stem), batch, 3, size, size,
-                     64, 7, 2, 3, _lib.ACT["relu"], dt, keep=(self.x, stem))
+            stem = _resnet_stem(bld, self.x, W, batch, size, ho, dt)
             hp = (ho + 2 - 3) // 2 + 1
             h = bld.buf((batch, hp, hp, 64))
             plan.add(lib.advs_maxpool3x3s2, ptr(stem), ptr(h), batch, ho, ho, 64, dt, keep=(stem, h))
@@ -281,8 +294,10 @@ class _ResNetGradEngine:
                 g = gh
             gs = bld.buf(tuple(stem.shape))
             plan.add(lib.advs_maxpool3x3s2_bwd_relu, ptr(g), ptr(stem), ptr(gs), batch, ho, ho, 64, dt, keep=(g, stem, gs))
-            plan.add(lib.advs_conv_stem_bwd, ptr(gs), ptr(W["stem.w"]), ptr(self.grad), batch, 3, size, size, 64, 7, 2, 3, dt,
-                     keep=(gs, self.grad))
+            kp = G["stem.wT"].numel() // 64
+            gcol = bld.conv(gs, G["stem.wT"], kp, ksize=1, pad=0)          # gradient of the im2col columns
+            plan.add(lib.advs_col2im_nchw, ptr(gcol), ptr(self.grad), batch, 3, size, size, 7, 2, 3, kp, dt,
+                     keep=(gcol, self.grad))
             self.plan, self.captured = plan, False
             torch.cuda.synchronize(dev)
 

@@ -283,6 +283,11 @@ int advs_argmax_rows(const float* x, int* out, int rows, int n, void* stream);
 int advs_conv_stem(const float* x_nchw, const float* w_oihw, const float* bias, void* y,
                    int b, int cin, int h, int w, int cout, int ksize, int stride, int pad, int act,
                    int dtype, void* stream);
+/* The stem as a GEMM: y[b][oy][ox][k] = x[b][c][oy*stride+r-pad][ox*stride+s-pad] (0 outside the image), k = (c*ksize + r)*ksize + s,
+ * zero for k in [cin*ksize*ksize, kp).  The conv is then advs_conv2d 1x1 over kp channels with the OIHW weight viewed as
+ * [cout][cin*ksize*ksize] and zero-padded to kp (ResNet-50's 7x7 stride-2 conv1, ASR_fast.py:16-20, on MFMA).           */
+int advs_im2col_nchw(const float* x_nchw, void* y, int b, int cin, int h, int w, int ksize, int stride, int pad,
+                     int kp, int dtype, void* stream);
 int advs_maxpool3x3s2(const void* x, void* y, int b, int h, int w, int c, int dtype, void* stream); /* MaxPool2d(3,2,1) */
 int advs_global_avgpool(const void* x, float* y, int b, int hw, int c, int dtype, void* stream);    /* -> f32 [b][c] */
 
@@ -306,6 +311,10 @@ int advs_maxpool3x3s2_bwd_relu(const void* g, const void* x, void* out, int b, i
 /* data gradient of advs_conv_stem: g NHWC T [b][ho][wo][cout], w the same f32 OIHW weight -> dx NCHW f32 [b][cin][h][w] */
 int advs_conv_stem_bwd(const void* g, const float* w_oihw, float* dx_nchw, int b, int cin, int h, int w, int cout,
                        int ksize, int stride, int pad, int dtype, void* stream);
+/* Adjoint of advs_im2col_nchw: dx[b][c][iy][ix] = sum of gcol[b][oy][ox][(c*ksize + r)*ksize + s] over the taps that read
+ * that pixel; gcol [b][ho][wo][kp] T is advs_conv2d 1x1 of the stem-output gradient with the transposed stem weight.       */
+int advs_col2im_nchw(const void* gcol, float* dx_nchw, int b, int cin, int h, int w, int ksize, int stride, int pad,
+                     int kp, int dtype, void* stream);
 /* pert = clamp(pert - alpha * sign(sum_k grad[b][k] * mask), -eps, eps); x_in = x0 + pert (x_in may be NULL).
  * x0, pert, x_in NCHW f32 [b][c][hw]; grad [b][nsum][c][hw]; mask [b][mask_channels (1 | c)][hw].                   */
 int advs_iga_step(const float* x0, const float* grad, const float* mask, float* pert, float* x_in,

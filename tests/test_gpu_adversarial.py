@@ -72,6 +72,39 @@ def test_stem_data_gradient(dt):
 
 
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_stem_as_im2col_gemm_and_its_adjoint(dt):
+    """advs_im2col_nchw + 1x1 conv == the 7x7 stride-2 conv; 1x1 conv on the transposed weight + advs_col2im_nchw == its
+    data gradient (odd image sizes: taps fall off every border)."""
+    from advshadow_amd.engine import SLAB_ELEMS, pack_conv_weight, dtype_code
+    g = torch.Generator().manual_seed(21)
+    r = (lambda t: t.bfloat16().float()) if dt == "bf16" else (lambda t: t)
+    x = torch.rand(2, 3, 37, 41, generator=g)
+    w = r(torch.randn(64, 3, 7, 7, generator=g) * 0.05)
+    b = torch.randn(64, generator=g) * 0.1
+    xr = r(x).requires_grad_(True)
+    y = F.conv2d(xr, w, b, stride=2, padding=3)
+    gy = r(torch.randn(y.shape, generator=g))
+    y.backward(gy)
+    code = dtype_code(dt)
+    kp = -(-147 // SLAB_ELEMS[code]) * SLAB_ELEMS[code]
+    op = OneOp(dt, 2)
+    lib = op.b.lib
+    xd = x.to(dev())
+    cols = op.b.buf((2, y.shape[2], y.shape[3], kp))
+    op.b.plan.add(lib.advs_im2col_nchw, ptr(xd), ptr(cols), 2, 3, 37, 41, 7, 2, 3, kp, op.b.dt)
+    yd = op.b.conv(cols, pack_conv_weight(w.reshape(64, 147, 1, 1).to(dev()), code), 64, bias=b.to(dev()), ksize=1, pad=0)
+    wt = torch.zeros(kp, 64)
+    wt[:147] = w.reshape(64, 147).t()
+    gcol = op.b.conv(nhwc(gy, dt), pack_conv_weight(wt.reshape(kp, 64, 1, 1).to(dev()), code), kp, ksize=1, pad=0)
+    dx = torch.empty(2, 3, 37, 41, device=dev())
+    op.b.plan.add(lib.advs_col2im_nchw, ptr(gcol), ptr(dx), 2, 3, 37, 41, 7, 2, 3, kp, op.b.dt)
+    op.go()
+    assert (nchw(yd) - y.detach()).abs().max().item() < (2e-5 if dt == "fp32" else 3e-2)
+    scale = xr.grad.abs().max().item()
+    assert (dx.cpu() - xr.grad).abs().max().item() < (2e-5 if dt == "fp32" else 2e-2) * scale
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
 def test_zero_insert_and_relu_backward(dt):
     g = torch.Generator().manual_seed(3)
     op = OneOp(dt, 2)
