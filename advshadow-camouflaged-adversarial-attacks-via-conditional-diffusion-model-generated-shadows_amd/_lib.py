@@ -87,6 +87,7 @@ SIGNATURES = {
     "advs_zero_insert2x": [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "advs_avgpool_bwd_relu": [vp, vp, vp, i32, i32, i32, i32, vp],
     "advs_maxpool3x3s2_bwd_relu": [vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "advs_maxpool2_bwd_relu": [vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "advs_conv_stem_bwd": [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "advs_iga_step": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, f32, vp],
     "advs_perturb_clamp01": [vp, vp, vp, C.c_longlong, vp],

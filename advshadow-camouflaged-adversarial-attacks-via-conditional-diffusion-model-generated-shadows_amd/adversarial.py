@@ -7,8 +7,9 @@ reference calls ``loss.backward()`` and reads ``image.grad``, this runs the vict
 ReLU / stem backward are the kernels of ``csrc/victim_grad.hip``), replayed as one hipGraph per iteration; the sign
 update and clamps are ``advs_iga_step`` / ``advs_perturb_clamp01``.  There is no autograd and no CPU fallback.
 
-The classifier must be (or wrap, as ``classifier.model``) an ``advshadow_amd.victims.ResNet50`` -- the architecture
-of ddim2/test.py:22-36; the fastai learner pickle of tools/train_shadow.py:50 is not loadable here.
+The classifier must be (or wrap, as ``classifier.model``) a victim with a backward plan: ``advshadow_amd.victims.ResNet50``
+(the architecture of ddim2/test.py:22-36) or ``victims.VGG``; the fastai learner pickle of tools/train_shadow.py:50 is
+not loadable here.
 """
 import ctypes as C
 
@@ -24,7 +25,7 @@ def _victim(classifier):
     model = getattr(classifier, "model", classifier)
     if not hasattr(model, "grad_engine"):
         raise _lib.AdvsError(f"{type(model).__name__} has no HIP backward plan: the gradient attack needs an "
-                             "advshadow_amd.victims.ResNet50 (there is no autograd fallback)")
+                             "advshadow_amd.victims.ResNet50 or VGG (there is no autograd fallback)")
     return model
 
 

@@ -193,6 +193,61 @@ extern "C" int advs_maxpool3x3s2_bwd_relu(const void* g, const void* x, void* ou
     return ADVS_OK;
 }
 
+// ---------------------------------------------------------------- MaxPool2d(2) backward fused with the ReLU of its input
+// VGG's conv-ReLU-pool (ASR_fast.py:33-46 victims): x [b][h][w][c] is the pool's input (a conv output after ReLU), g the
+// gradient at [b][h/2][w/2][c].  Windows do not overlap: a pixel gets its window's g iff it is the window's first maximum
+// in row-major order (torch keeps the first) and x > 0; rows / columns beyond 2*(h/2), 2*(w/2) get none.
+template <typename T>
+__global__ void maxpool2_bwd_relu_kernel(const u32x4* __restrict__ g, const u32x4* __restrict__ x, u32x4* __restrict__ out,
+                                         int B, int H, int W, int vpp) {
+    constexpr int VEC = Elt<T>::VEC;
+    const int Ho = H >> 1, Wo = W >> 1;
+    const size_t total = (size_t)B * H * W * vpp;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % vpp);
+        size_t r = i / vpp;
+        const int ix = (int)(r % W); r /= W;
+        const int iy = (int)(r % H);
+        const int b = (int)(r / H);
+        const int oy = iy >> 1, ox = ix >> 1;
+        float acc[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+        if (oy < Ho && ox < Wo) {
+            float best[VEC], me[VEC], gv[VEC];
+            bool mine[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { best[j] = -INFINITY; mine[j] = false; }
+            for (int q = 0; q < 4; ++q) {
+                const int yy = 2 * oy + (q >> 1), xx = 2 * ox + (q & 1);
+                float t[VEC];
+                unpack16<T>(x[(((size_t)b * H + yy) * W + xx) * vpp + cv], t);
+                const bool self = yy == iy && xx == ix;
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    if (self) me[j] = t[j];
+                    if (t[j] > best[j]) { best[j] = t[j]; mine[j] = self; }
+                }
+            }
+            unpack16<T>(g[(((size_t)b * Ho + oy) * Wo + ox) * vpp + cv], gv);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc[j] = (mine[j] && me[j] > 0.f) ? gv[j] : 0.f;
+        }
+        out[i] = pack16<T>(acc);
+    }
+}
+
+extern "C" int advs_maxpool2_bwd_relu(const void* g, const void* x, void* out, int b, int h, int w, int c, int dtype, void* stream) {
+    ADVS_REQUIRE(dtype_ok(dtype), "advs_maxpool2_bwd_relu: unknown dtype code %d", dtype);
+    const int vec = dtype == ADVS_F32 ? 4 : 8;
+    ADVS_REQUIRE(g && x && out && b > 0 && h > 1 && w > 1 && c > 0 && c % vec == 0, "maxpool2_bwd_relu: bad args");
+    const size_t total = (size_t)b * h * w * (c / vec);
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    ADVS_SWITCH_T(dtype, maxpool2_bwd_relu_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>((const u32x4*)g, (const u32x4*)x, (u32x4*)out, b, h, w, c / vec));
+    ADVS_CHECK_LAUNCH("maxpool2_bwd_relu");
+    return ADVS_OK;
+}
+
 // ---------------------------------------------------------------- stem conv data gradient: NHWC T -> NCHW f32 image
 // dx[b][c][iy][ix] = sum_{r,s,o} g[b][(iy + pad - r) / stride][(ix + pad - s) / stride][o] * w[o][c][r][s]
 // over the (r, s) for which both quotients are exact and in range.  thread = one image pixel, all cin (<= 4) channels;

@@ -17,7 +17,29 @@ from .engine import SLAB_ELEMS, Builder, dtype_code, pack_conv_weight, ptr
 _LAYERS = ((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2))     # (width, blocks, stride of first block)
 
 
-class ResNet50(nn.Module):
+class _InputGradient:
+    """Victims with a HIP backward-to-the-image plan (``grad_engine``)."""
+
+    def input_gradient(self, x, labels):
+        """x [B,3,H,W] f32, labels [B] int64 (GPU) -> (logits [B,K], d cross_entropy(logits_b, label_b) / d x_b [B,3,H,W]):
+        what ``loss.backward(); image.grad`` yields for a batch of one in tools/train_shadow.py:204-212, per image."""
+        B, _, H, Wd = x.shape
+        assert H == Wd, "square inputs only"
+        eng = self.grad_engine(B, H)
+        cur = torch.cuda.current_stream(x.device)
+        eng.stream.wait_stream(cur)
+        with torch.cuda.stream(eng.stream):
+            eng.x.copy_(x.to(torch.float32), non_blocking=True)
+            eng.labels.copy_(labels.to(torch.int64).reshape(B), non_blocking=True)
+            eng.run()
+            out, grad = eng.logits.clone(), eng.grad.clone()
+        cur.wait_stream(eng.stream)
+        out.record_stream(cur)
+        grad.record_stream(cur)
+        return out, grad
+
+
+class ResNet50(_InputGradient, nn.Module):
     def __init__(self, num_classes=37, compute_dtype="fp32", use_graph=True):
         super().__init__()
         self.num_classes, self.compute_dtype, self.use_graph = num_classes, compute_dtype, use_graph
@@ -129,24 +151,6 @@ class ResNet50(nn.Module):
             eng = _ResNetGradEngine(self, W, G, batch, size, dt)
             self._engines[("grad", batch, size, dt)] = eng
         return eng
-
-    def input_gradient(self, x, labels):
-        """x [B,3,H,W] f32, labels [B] int64 (GPU) -> (logits [B,K], d cross_entropy(logits_b, label_b) / d x_b [B,3,H,W]):
-        what ``loss.backward(); image.grad`` yields for a batch of one in tools/train_shadow.py:204-212, per image."""
-        B, _, H, Wd = x.shape
-        assert H == Wd, "square inputs only"
-        eng = self.grad_engine(B, H)
-        cur = torch.cuda.current_stream(x.device)
-        eng.stream.wait_stream(cur)
-        with torch.cuda.stream(eng.stream):
-            eng.x.copy_(x.to(torch.float32), non_blocking=True)
-            eng.labels.copy_(labels.to(torch.int64).reshape(B), non_blocking=True)
-            eng.run()
-            out, grad = eng.logits.clone(), eng.grad.clone()
-        cur.wait_stream(eng.stream)
-        out.record_stream(cur)
-        grad.record_stream(cur)
-        return out, grad
 
     def forward(self, x):
         """x [B,3,H,W] f32 on the GPU -> logits [B,num_classes] f32."""
@@ -502,7 +506,7 @@ _VGG_CFG = {16: [64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, 
             19: [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M"]}
 
 
-class VGG(nn.Module):
+class VGG(_InputGradient, nn.Module):
     """torchvision ``vgg16()`` / ``vgg19()`` with ``classifier[6] = Linear(4096, 37)`` (ASR_fast.py:33-46):
     ``features.{i}`` convs (bias + ReLU in the conv epilogue), MaxPool2d(2), three Linear layers."""
 
@@ -542,7 +546,7 @@ class VGG(nn.Module):
         for i in (0, 3, 6):
             W[f"fc{i}.w"], W[f"fc{i}.b"] = sd[f"classifier.{i}.weight"].float().contiguous(), sd[f"classifier.{i}.bias"].float().contiguous()
         self._packed[dt] = (ver, W)
-        for key in [k for k in self._engines if k[2] == dt]:
+        for key in [k for k in self._engines if k[-1] == dt]:
             del self._engines[key]
         return W
 
@@ -553,6 +557,34 @@ class VGG(nn.Module):
         if eng is None:
             eng = _VGGEngine(self, W, batch, size, dt)
             self._engines[(batch, size, dt)] = eng
+        return eng
+
+    def packed_grad_weights(self, dt):
+        """Data-gradient weights: 3x3 convs transposed and flipped, classifier matrices transposed."""
+        ver = self._version()
+        hit = self._packed.get(("grad", dt))
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        self.packed_weights(dt)
+        sd = {k: v.detach() for k, v in self.state_dict().items()}
+        G = {}
+        for kind, p, cin, cout in self.layers:
+            if kind == "conv" and cin != 3:
+                G[p + ".wT"] = pack_conv_weight(sd[p + ".weight"].float().permute(1, 0, 2, 3).flip(2, 3).contiguous(), dt)
+        for i in (0, 3, 6):
+            G[f"fc{i}.wT"] = sd[f"classifier.{i}.weight"].float().t().contiguous()
+        self._packed[("grad", dt)] = (ver, G)
+        return G
+
+    def grad_engine(self, batch, size, dtype=None):
+        if size != 224:
+            raise ValueError("VGG victim expects 224x224 inputs (AdaptiveAvgPool2d(7) is the identity there)")
+        dt = dtype_code(dtype if dtype is not None else self.compute_dtype)
+        W, G = self.packed_weights(dt), self.packed_grad_weights(dt)
+        eng = self._engines.get(("grad", batch, size, dt))
+        if eng is None:
+            eng = _VGGGradEngine(self, W, G, batch, size, dt)
+            self._engines[("grad", batch, size, dt)] = eng
         return eng
 
     def forward(self, x):
@@ -600,6 +632,83 @@ class _VGGEngine(_ResNetEngine):
             self.logits = bld.linear(f, W["fc6.w"], W["fc6.b"])
             self.plan, self.captured = bld.plan, False
             torch.cuda.synchronize(dev)
+
+
+class _VGGGradEngine:
+    """VGG forward with every activation retained, then backwards to the image.  ``g`` entering a conv layer is the
+    gradient of its pre-ReLU output: the ReLU mask is applied by the layer behind it -- ``advs_maxpool2_bwd_relu`` when
+    that is a pool, otherwise the next conv's data-gradient conv (epilogue ``relu_mask``, or ``advs_relu_bwd`` after the
+    halo kernel where the map is a multiple of 16)."""
+
+    def __init__(self, model, W, G, batch, size, dt):
+        dev = next(model.parameters()).device
+        self.model, self.stream = model, torch.cuda.Stream(device=dev)
+        with torch.cuda.device(dev):
+            bld = Builder(dev, dt, self.stream, batch)
+            lib, plan = bld.lib, bld.plan
+            self.x = torch.zeros((batch, 3, size, size), dtype=torch.float32, device=dev)
+            self.labels = torch.zeros((batch,), dtype=torch.int64, device=dev)
+            self.grad = torch.zeros((batch, 3, size, size), dtype=torch.float32, device=dev)
+            h, hw, acts = None, size, []
+            for kind, p, cin, cout in model.layers:
+                if kind == "conv" and cin == 3:
+                    new = bld.buf((batch, hw, hw, cout))
+                    plan.add(lib.advs_conv_stem, ptr(self.x), ptr(W[p + ".w"]), ptr(W[p + ".b"]), ptr(new), batch, 3, hw, hw,
+                             cout, 3, 1, 1, _lib.ACT["relu"], dt, keep=(self.x, new))
+                elif kind == "conv":
+                    new = bld.conv(h, W[p + ".w"], cout, bias=W[p + ".b"], act="relu")
+                else:
+                    new = bld.maxpool2(h)
+                acts.append((kind, p, cin, cout, h, new, hw))
+                if kind == "pool":
+                    hw //= 2
+                h = new
+            flat = bld.buf((batch, 512, hw, hw), torch.float32)           # x.view(B, -1) flattens NCHW
+            plan.add(lib.advs_nhwc_to_nchw_f32, ptr(h), ptr(flat), batch, 512, hw, hw, dt, keep=(h, flat))
+            f0 = bld.linear(flat.view(batch, -1), W["fc0.w"], W["fc0.b"], act_out="relu")
+            f3 = bld.linear(f0, W["fc3.w"], W["fc3.b"], act_out="relu")
+            self.logits = bld.linear(f3, W["fc6.w"], W["fc6.b"])
+            # ---- backward: classifier
+            K = self.logits.shape[1]
+            gl = bld.buf((batch, K), torch.float32)
+            plan.add(lib.advs_softmax_ce_grad, ptr(self.logits), ptr(self.labels), ptr(gl), batch, K, 1.0,
+                     keep=(self.logits, self.labels, gl))
+
+            def relu_bwd(t, y, code):
+                plan.add(lib.advs_relu_bwd, ptr(t), 0, ptr(y), ptr(t), t.numel(), code, keep=(t, y))
+
+            g3 = bld.linear(gl, G["fc6.wT"], None)
+            relu_bwd(g3, f3, _lib.F32)
+            g0 = bld.linear(g3, G["fc3.wT"], None)
+            relu_bwd(g0, f0, _lib.F32)
+            gflat = bld.linear(g0, G["fc0.wT"], None)                     # [B, 512*hw*hw] = NCHW
+            g = bld.buf((batch, hw, hw, 512))
+            plan.add(lib.advs_nchw_f32_to_nhwc, ptr(gflat), ptr(g), batch, 512, hw, hw, dt, keep=(gflat, g))
+            # ---- backward: features
+            for i in range(len(acts) - 1, -1, -1):
+                kind, p, cin, cout, hin, hout, hwi = acts[i]
+                if kind == "pool":
+                    gi = bld.buf(tuple(hin.shape))
+                    plan.add(lib.advs_maxpool2_bwd_relu, ptr(g), ptr(hin), ptr(gi), batch, hwi, hwi, hin.shape[3], dt,
+                             keep=(g, hin, gi))
+                elif cin == 3:
+                    plan.add(lib.advs_conv_stem_bwd, ptr(g), ptr(W[p + ".w"]), ptr(self.grad), batch, 3, hwi, hwi, cout, 3, 1, 1,
+                             dt, keep=(g, self.grad))
+                    break
+                else:
+                    masked = acts[i - 1][0] == "conv"             # hin is a conv output: its ReLU is applied here
+                    if masked and hwi % 16 == 0:
+                        gi = bld.conv(g, G[p + ".wT"], cin)
+                        relu_bwd(gi, hin, dt)
+                    else:
+                        gi = bld.conv(g, G[p + ".wT"], cin, relu_mask=hin if masked else None)
+                bld.free(g)
+                bld.free(hout)
+                g = gi
+            self.plan, self.captured = plan, False
+            torch.cuda.synchronize(dev)
+
+    run = _ResNetEngine.run
 
 
 # ============================================================================ ConvNeXt (timm names)

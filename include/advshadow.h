@@ -308,6 +308,9 @@ int advs_avgpool_bwd_relu(const float* gp, const void* y, void* out, int b, int 
 /* MaxPool2d(3,2,1) backward (first maximum of a window gets its gradient, as torch) times [x > 0]; x [b][h][w][c] is
  * the pool's input (the stem output after ReLU), g the gradient at the pooled resolution.                            */
 int advs_maxpool3x3s2_bwd_relu(const void* g, const void* x, void* out, int b, int h, int w, int c, int dtype, void* stream);
+/* MaxPool2d(2) backward (first maximum of each 2x2 window, as torch) times [x > 0]; x [b][h][w][c] is the pool's input
+ * (a conv output after ReLU: VGG of ASR_fast.py:33-46), g the gradient at [b][h/2][w/2][c].                              */
+int advs_maxpool2_bwd_relu(const void* g, const void* x, void* out, int b, int h, int w, int c, int dtype, void* stream);
 /* data gradient of advs_conv_stem: g NHWC T [b][ho][wo][cout], w the same f32 OIHW weight -> dx NCHW f32 [b][cin][h][w] */
 int advs_conv_stem_bwd(const void* g, const float* w_oihw, float* dx_nchw, int b, int cin, int h, int w, int cout,
                        int ksize, int stride, int pad, int dtype, void* stream);

@@ -14,21 +14,22 @@ from .shadow import gaussian_blur_reflect101
 from .victims import resnet50_logits
 
 
-def input_gradient(sd, x, labels):
-    """d cross_entropy(model(x_b), label_b) / d x_b for every image of the batch (train_shadow.py:204-212, batch of one)."""
+def input_gradient(sd, x, labels, logits_fn=None):
+    """d cross_entropy(model(x_b), label_b) / d x_b for every image of the batch (train_shadow.py:204-212, batch of one).
+    ``logits_fn(sd, x)``: the functional victim, ResNet-50 by default."""
     x = x.clone().requires_grad_(True)
-    logits = resnet50_logits(sd, x)
+    logits = (logits_fn or resnet50_logits)(sd, x)
     F.cross_entropy(logits, labels, reduction="sum").backward()
     return logits.detach(), x.grad.detach()
 
 
 def apply_adversarial_perturbation(sd, original_image, label, feature_mask, epsilon=0.05, alpha=0.005, iterations=20,
-                                   grads=None):
+                                   grads=None, logits_fn=None):
     """train_shadow.py:177-221.  ``grads`` (optional list) receives each iteration's masked gradient."""
     image = original_image[None]
     pert = torch.zeros_like(image)
     for _ in range(iterations):
-        _, g = input_gradient(sd, image + pert, label)
+        _, g = input_gradient(sd, image + pert, label, logits_fn)
         gm = g * feature_mask
         if grads is not None:
             grads.append(gm[0])

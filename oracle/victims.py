@@ -60,9 +60,8 @@ VGG_CFG = {16: [64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "
            19: [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M"]}
 
 
-@torch.no_grad()
-def vgg_forward(sd, x, depth=16):
-    """torchvision VGG (features / avgpool / classifier), eval mode.  PARITY UNPINNED (torchvision absent)."""
+def vgg_logits(sd, x, depth=16):
+    """torchvision VGG (features / avgpool / classifier), eval mode, autograd left on.  PARITY UNPINNED (torchvision absent)."""
     idx = 0
     for v in VGG_CFG[depth]:
         if v == "M":
@@ -75,6 +74,11 @@ def vgg_forward(sd, x, depth=16):
     x = F.relu(F.linear(x, sd["classifier.0.weight"], sd["classifier.0.bias"]))
     x = F.relu(F.linear(x, sd["classifier.3.weight"], sd["classifier.3.bias"]))
     return F.linear(x, sd["classifier.6.weight"], sd["classifier.6.bias"])
+
+
+@torch.no_grad()
+def vgg_forward(sd, x, depth=16):
+    return vgg_logits(sd, x, depth)
 
 
 def hf_vit(num_labels=37, seed=2, **cfg):

@@ -270,3 +270,73 @@ def test_position_search_ddim2_variant():
     assert torch.equal(c, c_ref) and abs(float(r) - float(r_ref)) < 1e-6 and float(r) > 15.0
     assert (im.cpu() - im_ref).abs().max().item() <= 4 * 0.01 + 1e-6
     assert ((im.cpu() - im_ref).abs() < 1e-6).float().mean().item() > 0.9
+
+
+# ------------------------------------------------------------------------------ VGG16 victim (ASR_fast.py:33-46)
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("hw", [(14, 14), (7, 9)])
+def test_maxpool2_backward_with_relu(dt, hw):
+    g = torch.Generator().manual_seed(31)
+    z = torch.randn(2, 64, *hw, generator=g)
+    if dt == "bf16":
+        z = z.bfloat16().float()
+    z.requires_grad_(True)
+    y = F.max_pool2d(F.relu(z), 2)
+    gy = torch.randn(y.shape, generator=g)
+    if dt == "bf16":
+        gy = gy.bfloat16().float()
+    y.backward(gy)
+    op = OneOp(dt, 2)
+    xd, gd = nhwc(F.relu(z.detach()), dt), nhwc(gy, dt)
+    out = op.b.buf((2, hw[0], hw[1], 64))
+    op.b.plan.add(op.b.lib.advs_maxpool2_bwd_relu, ptr(gd), ptr(xd), ptr(out), 2, hw[0], hw[1], 64, op.b.dt)
+    op.go()
+    assert torch.equal(nchw(out), z.grad)
+
+
+def _exact_vgg_state(net, seed):
+    """Sparse ternary weights and dyadic biases / inputs: every forward sum is exact in fp32 whatever its order, so the CPU
+    oracle and the GPU take identical ReLU / max-pool decisions.  (With generic weights a randomly initialised VGG16 has
+    ~13.5M pre-activations, a dozen of which fall within rounding of zero; each such mask flip moves the image gradient
+    by several percent -- measured on the CPU by perturbing the pre-activations by 3e-7 relative: 13 flips, 14 % L2.)"""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for k, v in net.state_dict().items():
+        if k.endswith("bias"):
+            sd[k] = torch.randint(-1, 2, v.shape, generator=g).float() / 16
+            continue
+        w = torch.zeros(v.shape)
+        flat = w.view(w.shape[0], -1)
+        taps = 6 if v.dim() == 4 else 8
+        cols = torch.randint(0, flat.shape[1], (flat.shape[0], taps), generator=g)
+        vals = torch.randint(0, 2, (flat.shape[0], taps), generator=g).float() * 2 - 1
+        flat.scatter_(1, cols, vals)
+        sd[k] = w / 64 if k.startswith("classifier.6") else w
+    return sd
+
+
+def test_vgg16_input_gradient_and_attack_match_autograd():
+    from advshadow_amd.victims import VGG
+    from oracle import victims as ov
+    net = VGG(16, 37)
+    sd = _exact_vgg_state(net, 6)
+    net.load_state_dict(sd)
+    net = net.to("cuda").eval()
+    g = torch.Generator().manual_seed(32)
+    x = torch.randint(0, 17, (1, 3, 224, 224), generator=g).float() / 16
+    ref_logits = ov.vgg_forward(sd, x)
+    labels = torch.tensor([(int(ref_logits.argmax()) + 5) % 37])
+    ref_logits, ref = oa.input_gradient(sd, x, labels, ov.vgg_logits)
+    logits, grad = net.input_gradient(x.to(dev()), labels.to(dev()))
+    assert torch.equal(logits.cpu(), ref_logits)                                        # exact arithmetic by construction
+    scale = ref.abs().max().item()
+    assert scale > 0 and (ref != 0).float().mean().item() > 0.05
+    assert (grad.cpu() - ref).abs().max().item() < 1e-3 * scale                         # fp32 parity bar
+    _, again = net.input_gradient(x.to(dev()), labels.to(dev()))
+    assert torch.equal(again, grad)
+    # the attack on top of it: dyadic step and bound keep the perturbed images exact too (two iterations: CPU oracle time)
+    m = _mask(224, 5)
+    ref_adv, ref_pert = oa.apply_adversarial_perturbation(sd, x[0], labels, m, 1 / 64, 1 / 256, 2, logits_fn=ov.vgg_logits)
+    got = adversarial.apply_adversarial_perturbation(net, x[0], labels, dev(), m, 1 / 64, 1 / 256, 2).cpu()
+    assert ((got - ref_adv).abs() < 1e-6).float().mean().item() > 0.97
+    assert (got - ref_adv).abs().max().item() <= 2 * (1 / 64) + 1e-6
