@@ -545,6 +545,12 @@ class VGG(_InputGradient, nn.Module):
                 W[p + ".b"] = sd[p + ".bias"].float().contiguous()
         for i in (0, 3, 6):
             W[f"fc{i}.w"], W[f"fc{i}.b"] = sd[f"classifier.{i}.weight"].float().contiguous(), sd[f"classifier.{i}.bias"].float().contiguous()
+        # classifier[0] / [3] as 1x1 convs on the MFMA kernels (the wave-per-output advs_linear_f32 re-reads the 411 MB
+        # matrix once per image).  x.view(B, -1) flattens NCHW; the pooled map is NHWC, so the columns are permuted once here.
+        w0 = W["fc0.w"].reshape(4096, 512, 7, 7).permute(0, 2, 3, 1).reshape(4096, 512 * 49)
+        W["fc0.wp"] = pack_conv_weight(w0.reshape(4096, -1, 1, 1), dt)
+        W["fc3.wp"] = pack_conv_weight(W["fc3.w"].reshape(4096, 4096, 1, 1), dt)
+        del W["fc0.w"], W["fc3.w"]
         self._packed[dt] = (ver, W)
         for key in [k for k in self._engines if k[-1] == dt]:
             del self._engines[key]
@@ -571,8 +577,16 @@ class VGG(_InputGradient, nn.Module):
         for kind, p, cin, cout in self.layers:
             if kind == "conv" and cin != 3:
                 G[p + ".wT"] = pack_conv_weight(sd[p + ".weight"].float().permute(1, 0, 2, 3).flip(2, 3).contiguous(), dt)
-        for i in (0, 3, 6):
-            G[f"fc{i}.wT"] = sd[f"classifier.{i}.weight"].float().t().contiguous()
+        w0 = sd["classifier.0.weight"].float().reshape(4096, 512, 7, 7).permute(0, 2, 3, 1).reshape(4096, 512 * 49)
+        G["fc0.wTp"] = pack_conv_weight(w0.t().contiguous().reshape(512 * 49, 4096, 1, 1), dt)     # -> gradient of the NHWC pooled map
+        G["fc3.wTp"] = pack_conv_weight(sd["classifier.3.weight"].float().t().contiguous().reshape(4096, 4096, 1, 1), dt)
+        G["fc6.wT"] = sd["classifier.6.weight"].float().t().contiguous()
+        first = self.layers[0][1]                              # the 3-channel conv: column gradients, then advs_col2im_nchw
+        w = sd[first + ".weight"].float()
+        kp = -(-27 // SLAB_ELEMS[dt]) * SLAB_ELEMS[dt]
+        wt = torch.zeros((kp, w.shape[0]), dtype=torch.float32, device=w.device)
+        wt[:27] = w.reshape(w.shape[0], 27).t()
+        G["stem.wT"] = pack_conv_weight(wt.reshape(kp, w.shape[0], 1, 1), dt)
         self._packed[("grad", dt)] = (ver, G)
         return G
 
@@ -603,6 +617,17 @@ class VGG(_InputGradient, nn.Module):
         return out
 
 
+def _vgg_classifier(bld, h, W, batch, dt):
+    """classifier[0..6] on the pooled NHWC map h [B,7,7,512]: two 1x1-conv GEMMs (bias + ReLU in the epilogue; the 128x128
+    tile gives the weight stream twice the workgroups of the 256x256 one at M = batch), then the small f32 linear."""
+    lib = bld.lib
+    f0 = bld.conv(h.view(batch, 1, 1, -1), W["fc0.wp"], 4096, bias=W["fc0.b"], ksize=1, pad=0, act="relu", tile=1)
+    f3 = bld.conv(f0, W["fc3.wp"], 4096, bias=W["fc3.b"], ksize=1, pad=0, act="relu", tile=1)
+    f3f = bld.buf((batch, 4096), torch.float32)
+    bld.plan.add(lib.advs_nhwc_to_nchw_f32, ptr(f3), ptr(f3f), batch, 4096, 1, 1, dt, keep=(f3, f3f))
+    return f0, f3, bld.linear(f3f, W["fc6.w"], W["fc6.b"])
+
+
 class _VGGEngine(_ResNetEngine):
     def __init__(self, model, W, batch, size, dt):
         dev = next(model.parameters()).device
@@ -625,11 +650,7 @@ class _VGGEngine(_ResNetEngine):
                 if h is not None:
                     bld.free(h)
                 h = new
-            flat = bld.buf((batch, 512, hw, hw), torch.float32)           # x.view(B, -1) flattens NCHW
-            bld.plan.add(lib.advs_nhwc_to_nchw_f32, ptr(h), ptr(flat), batch, 512, hw, hw, dt, keep=(h, flat))
-            f = bld.linear(flat.view(batch, -1), W["fc0.w"], W["fc0.b"], act_out="relu")
-            f = bld.linear(f, W["fc3.w"], W["fc3.b"], act_out="relu")
-            self.logits = bld.linear(f, W["fc6.w"], W["fc6.b"])
+            _, _, self.logits = _vgg_classifier(bld, h, W, batch, dt)
             self.plan, self.captured = bld.plan, False
             torch.cuda.synchronize(dev)
 
@@ -663,11 +684,7 @@ class _VGGGradEngine:
                 if kind == "pool":
                     hw //= 2
                 h = new
-            flat = bld.buf((batch, 512, hw, hw), torch.float32)           # x.view(B, -1) flattens NCHW
-            plan.add(lib.advs_nhwc_to_nchw_f32, ptr(h), ptr(flat), batch, 512, hw, hw, dt, keep=(h, flat))
-            f0 = bld.linear(flat.view(batch, -1), W["fc0.w"], W["fc0.b"], act_out="relu")
-            f3 = bld.linear(f0, W["fc3.w"], W["fc3.b"], act_out="relu")
-            self.logits = bld.linear(f3, W["fc6.w"], W["fc6.b"])
+            f0, f3, self.logits = _vgg_classifier(bld, h, W, batch, dt)
             # ---- backward: classifier
             K = self.logits.shape[1]
             gl = bld.buf((batch, K), torch.float32)
@@ -677,13 +694,12 @@ class _VGGGradEngine:
             def relu_bwd(t, y, code):
                 plan.add(lib.advs_relu_bwd, ptr(t), 0, ptr(y), ptr(t), t.numel(), code, keep=(t, y))
 
-            g3 = bld.linear(gl, G["fc6.wT"], None)
-            relu_bwd(g3, f3, _lib.F32)
-            g0 = bld.linear(g3, G["fc3.wT"], None)
-            relu_bwd(g0, f0, _lib.F32)
-            gflat = bld.linear(g0, G["fc0.wT"], None)                     # [B, 512*hw*hw] = NCHW
-            g = bld.buf((batch, hw, hw, 512))
-            plan.add(lib.advs_nchw_f32_to_nhwc, ptr(gflat), ptr(g), batch, 512, hw, hw, dt, keep=(gflat, g))
+            g3f = bld.linear(gl, G["fc6.wT"], None)
+            g3 = bld.buf((batch, 1, 1, 4096))
+            plan.add(lib.advs_nchw_f32_to_nhwc, ptr(g3f), ptr(g3), batch, 4096, 1, 1, dt, keep=(g3f, g3))
+            relu_bwd(g3, f3, dt)
+            g0 = bld.conv(g3, G["fc3.wTp"], 4096, ksize=1, pad=0, relu_mask=f0, tile=1)
+            g = bld.conv(g0, G["fc0.wTp"], 512 * hw * hw, ksize=1, pad=0, tile=1).view(batch, hw, hw, 512)
             # ---- backward: features
             for i in range(len(acts) - 1, -1, -1):
                 kind, p, cin, cout, hin, hout, hwi = acts[i]
@@ -692,8 +708,10 @@ class _VGGGradEngine:
                     plan.add(lib.advs_maxpool2_bwd_relu, ptr(g), ptr(hin), ptr(gi), batch, hwi, hwi, hin.shape[3], dt,
                              keep=(g, hin, gi))
                 elif cin == 3:
-                    plan.add(lib.advs_conv_stem_bwd, ptr(g), ptr(W[p + ".w"]), ptr(self.grad), batch, 3, hwi, hwi, cout, 3, 1, 1,
-                             dt, keep=(g, self.grad))
+                    kp = G["stem.wT"].numel() // cout
+                    gcol = bld.conv(g, G["stem.wT"], kp, ksize=1, pad=0)
+                    plan.add(lib.advs_col2im_nchw, ptr(gcol), ptr(self.grad), batch, 3, hwi, hwi, 3, 1, 1, kp, dt,
+                             keep=(gcol, self.grad))
                     break
                 else:
                     masked = acts[i - 1][0] == "conv"             # hin is a conv output: its ReLU is applied here
