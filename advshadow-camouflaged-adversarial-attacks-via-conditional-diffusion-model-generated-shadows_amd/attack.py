@@ -31,12 +31,26 @@ def to_64(images_f32_nchw):
 
 
 def attack_shard(sample_fn, victim, clean, feature_masks, centers, radii, shadow_intensity=0.43, blur_kernel_size=5,
-                 win_size=7, jpeg_quality=None):
-    """One shard: returns (generated uint8 [n,3,S,S], pred int32 [n], psnr f32 [n], ssim f32 [n])."""
+                 win_size=7, jpeg_quality=None, gradient_attack=None):
+    """One shard: returns (generated uint8 [n,3,S,S], pred int32 [n], psnr f32 [n], ssim f32 [n]).
+
+    ``gradient_attack`` = dict(labels=[n] int64, epsilon=0.01, alpha=0.005, iterations=20) makes the composite the
+    classifier branch of ``apply_shadow`` (tools/train_shadow.py:242-266: shadow + iterative-gradient perturbation inside
+    the combined mask, on the victim's HIP backward plan) instead of the closed-form shadow; the victim must be a
+    ``ResNet50`` / ``VGG``.  Images are independent, so the shard boundaries of ``run_attack`` apply unchanged."""
     generated = sample_fn()                                           # DDIM sampler output, uint8 on the GPU
     # [.jpg round trip, as generate()'s default image_format implies ->] resize 224 -> victim -> argmax
     pred = evaluate_batch(generated, victim, jpeg_quality=jpeg_quality)
-    shadowed = apply_shadow_batch(clean, centers, radii, feature_masks, shadow_intensity, blur_kernel_size)
+    if gradient_attack is None:
+        shadowed = apply_shadow_batch(clean, centers, radii, feature_masks, shadow_intensity, blur_kernel_size)
+    else:
+        from .adversarial import apply_shadow_adversarial_batch
+        ga = dict(gradient_attack)
+        shadowed = apply_shadow_adversarial_batch(victim, clean, centers, radii, feature_masks, ga.pop("labels"),
+                                                  shadow_intensity, ga.pop("epsilon", 0.01), blur_kernel_size,
+                                                  ga.pop("alpha", 0.005), ga.pop("iterations", 20))
+        if ga:
+            raise TypeError(f"attack_shard: unknown gradient_attack keys {sorted(ga)}")
     sp = ssim_psnr_batch(to_64(clean), to_64(shadowed), win_size)     # [n,2] f64 (ssim, psnr)
     return generated, pred, sp[:, 1].float(), sp[:, 0].float()
 

@@ -58,3 +58,36 @@ def test_attack_loop_matches_oracle_pipeline():
         assert abs(float(ssim[i]) - s) < 1e-5 and abs(float(psnr[i]) - p) < 1e-3
     m, _ = attack.run_attack(n, lambda lo, hi: (gen, pred, psnr, ssim), labels=torch.arange(n) % 37)
     assert m["n"] == n and 0.0 <= m["asr"] <= 1.0 and m["psnr"] > 0
+
+
+def test_attack_shard_with_gradient_attack_composite():
+    """gradient_attack= switches the composite to the classifier branch of apply_shadow (train_shadow.py:242-266):
+    equals the direct call, stays within epsilon * mask of the closed-form shadow, and is shard-invariant."""
+    from advshadow_amd import adversarial, shadow
+    n, S = 4, 64
+    torch.manual_seed(1)
+    victim = ResNet50(37)
+    victim.load_state_dict(ov.randomize_bn({k: v.clone() for k, v in victim.state_dict().items()}, 9))
+    victim = victim.to("cuda").eval()
+    g = torch.Generator().manual_seed(8)
+    clean = torch.rand(n, 3, S, S, generator=g).cuda()
+    fmask = (torch.rand(n, 1, S, S, generator=g) > 0.2).float().cuda()
+    centers, radii = torch.tensor([[30.0, 34.0]] * n), torch.tensor([14.0] * n)
+    labels = torch.arange(n) % 37
+    gen0 = torch.zeros(n, 3, S, S, dtype=torch.uint8, device="cuda")
+    ga = dict(labels=labels, epsilon=0.01, alpha=0.005, iterations=5)
+    _, pred, psnr, ssim = attack.attack_shard(lambda: gen0, victim, clean, fmask, centers, radii, gradient_attack=ga)
+    direct = adversarial.apply_shadow_adversarial_batch(victim, clean, centers, radii, fmask, labels, iterations=5)
+    plain = shadow.apply_shadow_batch(clean, centers, radii, fmask)
+    assert (direct - plain).abs().max().item() <= 0.01 + 1e-6 and not torch.equal(direct, plain)
+    from advshadow_amd.metrics import ssim_psnr_batch
+    sp = ssim_psnr_batch(attack.to_64(clean), attack.to_64(direct), 7)
+    assert torch.equal(psnr, sp[:, 1].float()) and torch.equal(ssim, sp[:, 0].float())
+    # two shards of two images give the same per-image numbers
+    for lo in (0, 2):
+        sl = slice(lo, lo + 2)
+        _, _, p2, s2 = attack.attack_shard(lambda: gen0[sl], victim, clean[sl], fmask[sl], centers[sl], radii[sl],
+                                           gradient_attack=dict(ga, labels=labels[sl]))
+        assert torch.equal(p2, psnr[sl]) and torch.equal(s2, ssim[sl])
+    with pytest.raises(TypeError):
+        attack.attack_shard(lambda: gen0, victim, clean, fmask, centers, radii, gradient_attack=dict(ga, step=1))
