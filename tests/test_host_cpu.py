@@ -94,3 +94,23 @@ def test_base_diffusion_schedules_match_reference(golden):
     assert xt.shape == x.shape and torch.allclose(xt, torch.sqrt(1 - d.alpha_hat[[1, 500, 999]])[:, None, None, None] * eps)
     t = d.sample_time_steps(64)
     assert t.shape == (64,) and int(t.min()) >= 1 and int(t.max()) < 1000
+
+
+def test_gradient_attack_host_logic():
+    """adversarial.py's argument handling needs no GPU: victims without a HIP backward plan are refused (no autograd
+    fallback), feature masks are broadcast to [B, 1|C, H, W] or rejected."""
+    from advshadow_amd import AdvsError, adversarial
+    with pytest.raises(AdvsError, match="no HIP backward plan"):
+        adversarial._victim(object())
+
+    class Wrapped:
+        model = object()
+    with pytest.raises(AdvsError, match="no HIP backward plan"):
+        adversarial._victim(Wrapped())
+    cpu = torch.device("cpu")
+    assert adversarial._mask4(torch.ones(8, 8), 2, 3, 8, 8, cpu).shape == (2, 1, 8, 8)
+    assert adversarial._mask4(torch.ones(3, 8, 8), 1, 3, 8, 8, cpu).shape == (1, 3, 8, 8)
+    with pytest.raises(ValueError):
+        adversarial._mask4(torch.ones(2, 8, 8), 1, 3, 8, 8, cpu)
+    with pytest.raises(ValueError):
+        adversarial._mask4(torch.ones(1, 8, 9), 1, 3, 8, 8, cpu)
