@@ -16,6 +16,17 @@ from ... import _lib
 from ...engine import Plan, ptr
 
 
+def guidance_mode(labels, cfg_scale, where):
+    """Which forwards one sampler step needs (``where`` = the reference line for the error text).  With ``labels=None`` the
+    reference calls ``model(x, t, None)`` for both branches and ``lerp(u, u, w)`` is ``u`` exactly, so that case is
+    the unconditional plan whatever ``cfg_scale`` is -- never a conditional forward on stale labels."""
+    if labels is None:
+        return "uncond"
+    if cfg_scale is None:
+        raise TypeError(f"cfg_scale must be a number when labels are given ({where} compares it with 0)")
+    return "cfg" if cfg_scale > 0 else "cond"
+
+
 class BaseDiffusion:
     """model/samples/base.py:18-45: linear beta schedule in float32, alpha_hat = cumprod."""
 
@@ -76,18 +87,14 @@ class DDIMDiffusion(BaseDiffusion):
     def sample(self, model, n, labels=None, cfg_scale=None, x_T=None, clamp=False, return_float=False):
         dev = next(model.parameters()).device
         model.eval()
-        if labels is None and cfg_scale is None:
-            mode = "uncond"
-        else:
-            if cfg_scale is None:
-                raise TypeError("cfg_scale must be a number when labels are given (ddim.py:83 compares it with 0)")
-            mode = "cfg" if cfg_scale > 0 else "cond"
+        mode = guidance_mode(labels, cfg_scale, "ddim.py:83")
         eng = model.engine(n)
-        key = (id(eng), mode, float(cfg_scale or 0.0))
+        cfg = float(cfg_scale or 0.0) if mode == "cfg" else 0.0
+        key = (id(eng), mode, cfg)
         loop = self._loops.get(key)
         if loop is None:
             coef, tseq = self._tables(dev)
-            loop = _Loop(eng, mode, float(cfg_scale or 0.0), coef, tseq)
+            loop = _Loop(eng, mode, cfg, coef, tseq)
             self._loops = {key: loop}
         if x_T is None:
             x_T = torch.randn((n, 3, self.img_size, self.img_size))

@@ -10,7 +10,7 @@ import torch
 
 from ... import _lib
 from ...engine import Plan, ptr
-from .ddim import BaseDiffusion
+from .ddim import BaseDiffusion, guidance_mode
 
 
 class DDPMDiffusion(BaseDiffusion):
@@ -23,12 +23,7 @@ class DDPMDiffusion(BaseDiffusion):
                return_float=False):
         dev = next(model.parameters()).device
         model.eval()
-        if labels is None and cfg_scale is None:
-            mode = "uncond"
-        else:
-            if cfg_scale is None:
-                raise TypeError("cfg_scale must be a number when labels are given (ddpm.py:69)")
-            mode = "cfg" if cfg_scale > 0 else "cond"
+        mode = guidance_mode(labels, cfg_scale, "ddpm.py:68")
         eng = model.engine(n)
         ts = list(reversed(range(1, self.noise_steps)))
         if steps is not None:

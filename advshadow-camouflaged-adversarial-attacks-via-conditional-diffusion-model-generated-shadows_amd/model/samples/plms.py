@@ -6,7 +6,7 @@ import torch
 
 from ... import _lib
 from ...engine import ptr
-from .ddim import BaseDiffusion
+from .ddim import BaseDiffusion, guidance_mode
 
 
 class PLMSDiffusion(BaseDiffusion):
@@ -22,12 +22,7 @@ class PLMSDiffusion(BaseDiffusion):
         dev = next(model.parameters()).device
         lib = _lib.load()
         model.eval()
-        if labels is None and cfg_scale is None:
-            mode = "uncond"
-        else:
-            if cfg_scale is None:
-                raise TypeError("cfg_scale must be a number when labels are given (plms.py:83)")
-            mode = "cfg" if cfg_scale > 0 else "cond"
+        mode = guidance_mode(labels, cfg_scale, "plms.py:88")
         cfg = float(cfg_scale or 0.0)
         eng = model.engine(n)
         cur_t = torch.stack([a for a, _ in self.time_step])

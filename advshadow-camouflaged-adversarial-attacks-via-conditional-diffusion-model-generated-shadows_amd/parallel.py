@@ -26,26 +26,29 @@ def image_noise(global_ids, shape, seed=1234, device="cpu"):
 
 
 def gather_results(pred, psnr, ssim, total):
-    """All-gather per-image (pred int32, psnr f32, ssim f32) from every rank into global order.
-    Shards may be ragged: each rank pads to the largest shard and the pad is dropped."""
+    """All-gather per-image records {pred: int32, psnr: f32, ssim: f32} (12 bytes) from every rank into global
+    order: one collective on an int32 [cap, 3] buffer whose last two columns carry the floats' bit patterns.
+    Shards may be ragged: each rank pads to the largest shard and the pad is dropped.  The buffer lives where the
+    backend can reach it: on the GPU for nccl (RCCL over xGMI), on the host for gloo (CPU tests, rehearsals)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return pred, psnr, ssim
     world = dist.get_world_size()
     cap = max(shard_bounds(total, r, world)[1] - shard_bounds(total, r, world)[0] for r in range(world))
-    dev = pred.device
-    rec = torch.zeros((cap, 3), dtype=torch.float32, device=dev)
+    out_dev = pred.device
+    dev = out_dev if dist.get_backend() == "nccl" else torch.device("cpu")
+    rec = torch.zeros((cap, 3), dtype=torch.int32, device=dev)
     n = pred.numel()
-    rec[:n, 0] = pred.to(torch.float32)
-    rec[:n, 1] = psnr.to(torch.float32)
-    rec[:n, 2] = ssim.to(torch.float32)
+    rec[:n, 0] = pred.to(dev, torch.int32)
+    rec[:n, 1] = psnr.to(dev, torch.float32).view(torch.int32)
+    rec[:n, 2] = ssim.to(dev, torch.float32).view(torch.int32)
     bufs = [torch.empty_like(rec) for _ in range(world)]
     dist.all_gather(bufs, rec)
     parts = []
     for r in range(world):
         lo, hi = shard_bounds(total, r, world)
         parts.append(bufs[r][:hi - lo])
-    allr = torch.cat(parts, 0)
-    return allr[:, 0].to(torch.int32), allr[:, 1], allr[:, 2]
+    allr = torch.cat(parts, 0).to(out_dev)
+    return allr[:, 0].contiguous(), allr[:, 1].contiguous().view(torch.float32), allr[:, 2].contiguous().view(torch.float32)
 
 
 def reduce_metrics(pred, labels, psnr, ssim):

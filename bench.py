@@ -9,28 +9,39 @@ N > 1 shards independent image batches across ranks (weak scaling, no data-path 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
+Launched WITHOUT torch.distributed.run and with --gpus N > 1, the parent starts its own N ranks (child
+processes, one per GPU, before the parent makes any GPU call) and relays rank 0's line.
+
+``--pipeline attack`` times BASELINE configs 2/3 instead: DDIM-50 -> uint8 -> resize 224 -> ResNet-50
+victim -> argmax, apply_shadow composite -> 64x64 -> PSNR/SSIM, then the all-gather of the per-image
+results over RCCL and the ASR/PSNR/SSIM reduction (default 64 images per GPU); the DDIM-only rate of
+the same run is reported beside it.
+
 Prints ONE JSON line on rank 0 (contract in the task statement), with a `roofline` object for the
 dominant kernel (the implicit-GEMM conv, MFMA-bound) measured with HIP events on the engine's
-stream, and a `cpu_baseline` object (the CPU oracle timed on the host cores, N=1 only).
+stream, a `cpu_baseline` object (the CPU oracle timed on the host cores, N=1 only) and, at N=1 in the
+default mode, `fp32_parity_path`: the same workload in the exact-f32 mode the <=1e-3 parity claim is made for.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
 PEAK_MFMA_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}     # MI355X_MICROARCH.md: dense peaks
 
 
 def conv_profile(eng, reps=2):
     """Time every launch of the plan with HIP events on the engine's stream (eager replay) and
-    return per-kernel totals: {entry point: [launches, total ms, algorithmic flops, algorithmic bytes]}."""
+    return per-kernel totals: {entry point: [launches, total ms, algorithmic flops, algorithmic bytes, executed flops]}.
+    Algorithmic = the reference layer's 2*M*N*K (an ``Upsample`` conv counts its 9 taps on the upsampled grid);
+    executed = what the kernel multiplies (the sub-pixel form runs 4 of those 9 taps)."""
     from advshadow_amd import _lib
     lib = _lib.load()
     s = eng.stream.cuda_stream
@@ -53,7 +64,7 @@ def conv_profile(eng, reps=2):
         for i, (fn, args) in enumerate(ops):
             ms = C.c_float()
             _lib.check(lib.advs_event_elapsed_ms(evs[i], evs[i + 1], C.byref(ms)))
-            t = totals.setdefault(fn.__name__, [0, 0.0, 0.0, 0.0])
+            t = totals.setdefault(fn.__name__, [0, 0.0, 0.0, 0.0, 0.0])
             t[0] += 1
             t[1] += ms.value
             if fn.__name__ == "advs_conv2d":
@@ -63,7 +74,9 @@ def conv_profile(eng, reps=2):
                 wo = (wl + 2 * a.pad - a.ksize) // a.stride + 1
                 # the fused shortcut (extra 1x1 operand) is the reference's separate Conv2d (diff_model.py:89,103)
                 k_total = a.ksize * a.ksize * (a.c1 + a.c2) + a.ce1 + a.ce2
+                k_exec = 4 * (a.c1 + a.c2) if a.upsample == 2 else k_total
                 t[2] += 2.0 * a.b * ho * wo * a.cout * k_total
+                t[4] += 2.0 * a.b * ho * wo * a.cout * k_exec
                 esz = 4 if a.dtype == 0 else 2
                 t[3] += esz * (a.b * a.h * a.w_ * (a.c1 + a.c2) + a.cout * k_total
                                + a.b * ho * wo * (a.cout * (2 if a.residual else 1) + a.ce1 + a.ce2))
@@ -71,9 +84,8 @@ def conv_profile(eng, reps=2):
         lib.advs_event_destroy(e)
     for t in totals.values():
         t[0] //= reps
-        t[1] /= reps
-        t[2] /= reps
-        t[3] /= reps
+        for k in range(1, 5):
+            t[k] /= reps
     return totals
 
 
@@ -118,6 +130,7 @@ def host_cores():
 def cpu_baseline(size, ddim_steps, budget_s=20.0):
     """The CPU oracle (oracle/lineage_b.py, torch-CPU fp32) on the host cores: B=1 forwards of the
     same network at the same resolution, extrapolated to a full ddim_steps-step image."""
+    import torch
     from oracle import lineage_b as ob
     cores = host_cores()
     torch.set_num_threads(cores)
@@ -138,26 +151,110 @@ def cpu_baseline(size, ddim_steps, budget_s=20.0):
                       f"{per_fwd:.3f} s/forward x {ddim_steps} steps per image"}
 
 
+# --------------------------------------------------------------------------- self-launch
+def child_env(rank, world, port, base=None):
+    """Environment of rank ``rank`` of a self-launched run (what torch.distributed.run would export)."""
+    env = dict(os.environ if base is None else base)
+    env.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world),
+                "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "ADVS_BENCH_CHILD": "1"})
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # dmabuf IPC only on this pool (RCCL needs it)
+    return env
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n, argv, script=None):
+    """Parent of a ``--gpus N`` run started without a launcher: N children, one rank per GPU.  Nothing here touches
+    the GPU (no HIP call, no torch.cuda query that initialises it), so no exec-after-init hazard; rank 0's stdout is
+    relayed as this process's stdout, the other ranks' goes to stderr.  Returns the exit code."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=child_env(r, n, port),
+                                      stdout=subprocess.PIPE if r == 0 else 2))            # fd 2: the parent's stderr
+    out0, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        try:
+            p.wait(timeout=120 if rc == 0 else 5)
+        except subprocess.TimeoutExpired:
+            p.kill()                                            # exactly the child started above
+            p.wait()
+        rc = rc or p.returncode
+    for ln in out0.decode().splitlines():                      # the JSON line to stdout, library chatter to stderr
+        print(ln, file=sys.stdout if ln.lstrip().startswith("{") else sys.stderr)
+    sys.stdout.flush()
+    return rc
+
+
+# --------------------------------------------------------------------------- the attack pipeline (configs 2/3)
+class AttackPipeline:
+    """BASELINE configs 2/3 on one rank: DDIM-50 -> uint8 -> [resize 224 -> ResNet-50 -> argmax],
+    apply_shadow closed form on synthetic clean images -> 64x64 -> PSNR/SSIM; then parallel.gather_results."""
+
+    def __init__(self, net, gd, dev, rank, world, B, S, ddim_steps, dtype):
+        import torch
+        from advshadow_amd import parallel
+        from advshadow_amd.victims import ResNet50
+        self.net, self.gd, self.B, self.S, self.steps, self.rank, self.world = net, gd, B, S, ddim_steps, rank, world
+        self.total = B * world
+        lo, hi = parallel.shard_bounds(self.total, rank, world)
+        self.xT = parallel.image_noise(range(lo, hi), (3, S, S)).to(dev)
+        self.labels = torch.arange(self.total) % 37
+        torch.manual_seed(1)
+        self.victim = ResNet50(37, compute_dtype=dtype).to(dev).eval()       # seed 1, eval-mode BN, 37 classes
+        g = torch.Generator().manual_seed(7)
+        self.clean = torch.rand(self.total, 3, S, S, generator=g)[lo:hi].to(dev)
+        yy, xx = torch.meshgrid(torch.arange(S), torch.arange(S), indexing="ij")
+        c, r = S / 2.0, S * 80.0 / 256.0
+        self.fmask = (((xx - c) ** 2 + (yy - c) ** 2) <= r * r).float()[None, None].expand(hi - lo, 1, S, S).contiguous().to(dev)
+        self.centers = torch.tensor([[c, c]] * (hi - lo))
+        self.radii = torch.tensor([S * 40.0 / 256.0] * (hi - lo))
+
+    def sample_u8(self):
+        import torch
+        from advshadow_amd import _lib
+        x = self.gd.ddim_sample(self.net, self.S, batch_size=self.B, ddim_timesteps=self.steps, x_T=self.xT, return_tensor=True)
+        out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+        _lib.check(_lib.load().advs_to_uint8(x.data_ptr(), out.data_ptr(), x.numel(), 1, torch.cuda.current_stream().cuda_stream))
+        return out
+
+    def step(self):
+        from advshadow_amd import attack
+        return attack.run_attack(self.total, lambda lo, hi: attack.attack_shard(self.sample_u8, self.victim, self.clean, self.fmask,
+                                                                                self.centers, self.radii),
+                                 self.labels, self.rank, self.world)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default 32; 64 with --pipeline attack)")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--pipeline", default="ddim", choices=["ddim", "attack"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-fp32-line", action="store_true")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))  # no GPU call has been made in this process
 
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
-        args.gpus = world
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus must agree")
     # one rank per GPU; ADVS_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (ranks
     # then share devices and the control plane runs over gloo; the numbers of such a run mean nothing)
     backend = os.environ.get("ADVS_BENCH_BACKEND", "nccl")
@@ -177,36 +274,68 @@ def main():
 
     from advshadow_amd.diff_model import GaussianDiffusion, UNetModel
 
-    torch.manual_seed(0)                                        # random-init weights of the named architecture
-    net = UNetModel(compute_dtype=args.dtype).to(dev).eval()
+    attack_mode = args.pipeline == "attack"
+    B, S = args.batch or (64 if attack_mode else 32), args.size
+
+    def build(dtype):
+        torch.manual_seed(0)                                    # random-init weights of the named architecture
+        return UNetModel(compute_dtype=dtype).to(dev).eval()
+
+    net = build(args.dtype)
     gd = GaussianDiffusion()                                    # cosine schedule (diff_model.py:290)
-    B, S = args.batch, args.size
     g = torch.Generator().manual_seed(1234 + rank)              # images are indexed globally: rank r owns [r*B, (r+1)*B)
     xT = torch.randn(B, 3, S, S, generator=g).to(dev)
 
-    def one_pass():
-        return gd.ddim_sample(net, S, batch_size=B, ddim_timesteps=args.ddim_steps, x_T=xT, return_tensor=True)
+    def ddim_pass(model=None):
+        return gd.ddim_sample(model or net, S, batch_size=B, ddim_timesteps=args.ddim_steps, x_T=xT, return_tensor=True)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        one_pass()
+    def timed(fn, steps, warmup):
+        """W untimed passes, then exactly K passes between barrier + synchronize; MAX over ranks."""
+        out = None
+        for _ in range(warmup):
+            out = fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = fn()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        return elapsed, out
+
     if args.warmup == 0:
         net.engine(B, S)                                        # build the plan outside the timed region
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = one_pass()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    assert torch.isfinite(out).all().item(), "non-finite samples"
+    workload = (f"DDIM-{args.ddim_steps} shadow generation, diff_model.UNetModel() defaults "
+                f"(35.7M params, random init seed 0), batch {B}/GPU, 3x{S}x{S}, cosine schedule, "
+                f"x_T resident in HBM, hipGraph-captured step, sample left on the device "
+                f"(the reference's final .cpu().numpy(), 25 MB per 32 images, is outside the timed region)")
+    extra_cfg = {}
+    if attack_mode:
+        pipe = AttackPipeline(net, gd, dev, rank, world, B, S, args.ddim_steps, args.dtype)
+        xT = pipe.xT
+        d_elapsed, out = timed(ddim_pass, args.steps, max(args.warmup, 1))
+        elapsed, res = timed(pipe.step, args.steps, max(args.warmup, 1))
+        metrics, pred = res
+        assert metrics["n"] == B * world and pred.numel() == B * world
+        workload = (f"attack loop (BASELINE configs 2/3): DDIM-{args.ddim_steps} + uint8 cast + Pillow-exact resize 224 + ResNet-50 "
+                    f"victim (seed 1, 37 classes) + argmax, apply_shadow closed form (radius 40, intensity 0.43, blur 5) on synthetic "
+                    f"clean images + 64x64 PSNR/SSIM, all-gather of (pred, psnr, ssim) over {backend if world > 1 else 'no collective (1 rank)'} "
+                    f"+ ASR/PSNR/SSIM reduction; batch {B}/GPU, 3x{S}x{S}, default UNetModel, x_T resident in HBM")
+        extra_cfg = {"pipeline": "attack", "ddim_only_images_per_s": world * B * args.steps / d_elapsed,
+                     "ddim_only_ms_per_step": 1e3 * d_elapsed / args.steps,
+                     "post_sampling_ms_per_step": 1e3 * (elapsed - d_elapsed) / args.steps,
+                     "asr": metrics["asr"], "psnr": metrics["psnr"], "ssim": metrics["ssim"]}
+    else:
+        elapsed, out = timed(ddim_pass, args.steps, args.warmup)
+        assert torch.isfinite(out).all().item(), "non-finite samples"
 
     line = {
         "metric": "shadow-images/sec @256x256 50-step DDIM",
@@ -216,33 +345,46 @@ def main():
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"DDIM-{args.ddim_steps} shadow generation, diff_model.UNetModel() defaults "
-                               f"(35.7M params, random init seed 0), batch {B}/GPU, 3x{S}x{S}, cosine schedule, "
-                               f"x_T resident in HBM, hipGraph-captured step",
-                   "batch_per_gpu": B, "image_size": S, "ddim_steps": args.ddim_steps,
-                   "parallelism": f"batch-shard x{world}"},
+        "config": dict({"workload": workload, "batch_per_gpu": B, "image_size": S, "ddim_steps": args.ddim_steps,
+                        "parallelism": f"batch-shard x{world}"}, **extra_cfg),
     }
     if rank == 0 and not args.no_roofline:
         eng = net.engine(B, S)
         tot = conv_profile(eng)
         c = tot["advs_conv2d"]
         fwd_ms = sum(t[1] for t in tot.values())
-        ach = c[2] / (c[1] * 1e-3) / 1e12
+        ach = c[4] / (c[1] * 1e-3) / 1e12                       # executed FLOPs / time: what the matrix cores did
+        alg = c[2] / (c[1] * 1e-3) / 1e12                       # the reference layers' FLOPs / time
         tr = conv_traffic_from_profiles()
         peak = PEAK_MFMA_TFLOPS[args.dtype]
         line["roofline"] = {"bound": "mfma", "kernel": "advs_conv2d (conv3x3_halo_kernel + conv_igemm_kernel)",
                             "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                            "algorithmic_tflops": alg, "algorithmic_frac": alg / peak,
+                            "note": "achieved/frac count EXECUTED MACs (the three sub-pixel Upsample convs run 4 of the "
+                                    "reference's 9 taps); algorithmic_* count the reference layers' 2MNK",
                             "traffic": tr["bytes_per_launch"] if tr else None, "traffic_unit": "bytes/launch",
                             "traffic_source": (tr["source"] + ": " + tr["note"]) if tr else None,
                             "algorithmic_bytes_per_launch": c[3] / c[0],
                             "launches_per_forward": c[0], "avg_launch_ms": c[1] / c[0],
                             "algorithmic_gflop_per_launch": c[2] / c[0] / 1e9,
+                            "executed_gflop_per_launch": c[4] / c[0] / 1e9,
                             "forward_ms_by_kernel": {k: round(v[1], 3) for k, v in sorted(tot.items())},
                             "forward_ms_total": round(fwd_ms, 3)}
+    if rank == 0 and world == 1 and not attack_mode and args.dtype != "fp32" and not args.no_fp32_line:
+        # the exact-f32 mode (v_mfma_f32_32x32x2_f32) the <=1e-3 parity statement is made for, same workload
+        net32 = build("fp32")
+        e32, _ = timed(lambda: ddim_pass(net32), 1, 1)
+        tot32 = conv_profile(net32.engine(B, S), reps=1)
+        c32 = tot32["advs_conv2d"]
+        ach32 = c32[4] / (c32[1] * 1e-3) / 1e12
+        line["fp32_parity_path"] = {"value": B / e32, "unit": "shadow-images/sec", "ms_per_step": 1e3 * e32, "steps": 1,
+                                    "conv_tflops": ach32, "peak": PEAK_MFMA_TFLOPS["fp32"], "frac": ach32 / PEAK_MFMA_TFLOPS["fp32"],
+                                    "forward_ms_total": round(sum(t[1] for t in tot32.values()), 3)}
+        del net32
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(S, args.ddim_steps)
     if rank == 0:
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()                                          # rank 0 is still profiling: leave together
         dist.destroy_process_group()

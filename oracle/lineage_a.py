@@ -122,8 +122,19 @@ def _sa(sd, p, x, act, heads=4):
     q, k, v = qkv.chunk(3, dim=-1)
     d = C // heads
     q, k, v = (u.reshape(B, H * W, heads, d).transpose(1, 2) for u in (q, k, v))
-    w = torch.softmax((q / math.sqrt(d)) @ k.transpose(-1, -2), dim=-1)
-    a = (w @ v).transpose(1, 2).reshape(B, H * W, C)
+    N = H * W
+    if B * heads * N * N <= (1 << 28):
+        w = torch.softmax((q / math.sqrt(d)) @ k.transpose(-1, -2), dim=-1)
+        a = w @ v
+    else:
+        # the same row-wise softmax, a block of queries at a time: at 256x256 the [4B, N, N] weights the reference
+        # materialises (attention.py:46-47) are 64 GiB per image for sa6 (N = 65 536)
+        a = torch.empty_like(q)
+        qs = q / math.sqrt(d)
+        step = max(1, (1 << 26) // N)
+        for i in range(0, N, step):
+            a[:, :, i:i + step] = torch.softmax(qs[:, :, i:i + step] @ k.transpose(-1, -2), dim=-1) @ v
+    a = a.transpose(1, 2).reshape(B, H * W, C)
     a = F.linear(a, sd[p + ".mha.out_proj.weight"], sd[p + ".mha.out_proj.bias"]) + tok
     f = F.layer_norm(a, (C,), sd[p + ".ff_self.0.weight"], sd[p + ".ff_self.0.bias"], eps=1e-5)
     f = _act(act)(F.linear(f, sd[p + ".ff_self.1.weight"], sd[p + ".ff_self.1.bias"]))

@@ -91,3 +91,80 @@ def test_attack_shard_with_gradient_attack_composite():
         assert torch.equal(p2, psnr[sl]) and torch.equal(s2, ssim[sl])
     with pytest.raises(TypeError):
         attack.attack_shard(lambda: gen0, victim, clean, fmask, centers, radii, gradient_attack=dict(ga, step=1))
+
+
+def test_config4_reduced_fp16_ddim100_vit_victim():
+    """BASELINE config 4 at reduced size: fp16 eps-predictor, ``ddim_sample(ddim_timesteps=100)`` -- the sequence
+    [1, 11, ..., 991] of diff_model.py:428-440, one captured step graph replayed 100 times -- then ``attack_shard`` with
+    the ViT victim (configvit.json's architecture: HF ViTForImageClassification, 37 labels, ASR_fast.py:47-58) in fp16.
+    Checked: the step sequence; replays are bit-identical (images, decisions, metrics); the fp32 ViT plan takes the same
+    top-1 decision as the installed transformers ViT on the SAME uint8 images for every image, the fp16 plan wherever
+    transformers' own top-1 margin exceeds twice the fp16 logit error bound of test_vit_victim_matches_hf_transformers
+    (random-init logits sit 0.01-0.08 apart; a tie inside the rounding error has no right answer); the fp16 sample
+    eps stays within 0.02 of the fp32 eps at the first, middle and last of the 100 steps (teacher-forced)."""
+    from advshadow_amd import _lib
+    from advshadow_amd.victims import ViTVictim
+    n, S = 4, 32
+    over = dict(model_channels=64, channel_mult=(1, 2), num_res_blocks=1, attention_resolutions=(2,), num_heads=4)
+    gd = GaussianDiffusion()
+    seq, prev = gd.ddim_sequences(1000, 100)
+    assert list(seq) == list(range(1, 992, 10)) and list(prev) == [0] + list(range(1, 982, 10))
+    xT = parallel.image_noise(range(n), (3, S, S))
+    g = torch.Generator().manual_seed(7)
+    clean = torch.rand(n, 3, S, S, generator=g).cuda()
+    yy, xx = torch.meshgrid(torch.arange(S), torch.arange(S), indexing="ij")
+    fmask = (((xx - 16.0) ** 2 + (yy - 16.0) ** 2) <= 10 ** 2).float()[None, None].expand(n, 1, S, S).contiguous().cuda()
+    centers, radii = torch.tensor([[16.0, 16.0]] * n), torch.tensor([5.0] * n)
+    hf = ov.hf_vit(37, seed=2)
+
+    def sampler(dt):
+        torch.manual_seed(3)
+        net = UNetModel(compute_dtype=dt, **over).to("cuda").eval()
+
+        def sample_fn():
+            x = gd.ddim_sample(net, S, batch_size=n, ddim_timesteps=100, x_T=xT, return_tensor=True)
+            out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+            _lib.check(_lib.load().advs_to_uint8(x.data_ptr(), out.data_ptr(), x.numel(), 1, torch.cuda.current_stream().cuda_stream))
+            return out
+        return net, sample_fn
+
+    def victim(dt):
+        v = ViTVictim(37, compute_dtype=dt)
+        v.load_state_dict(hf.state_dict())
+        return v.to("cuda").eval()
+
+    net16, fn16 = sampler("fp16")
+    v16 = victim("fp16")
+    gen, pred, psnr, ssim = attack.attack_shard(fn16, v16, clean, fmask, centers, radii)
+    gen2, pred2, psnr2, ssim2 = attack.attack_shard(fn16, v16, clean, fmask, centers, radii)     # graph replays
+    assert torch.equal(gen, gen2) and torch.equal(pred, pred2) and torch.equal(psnr, psnr2) and torch.equal(ssim, ssim2)
+    assert gen.dtype == torch.uint8 and gen.shape == (n, 3, S, S)
+    # the victim's decisions against transformers' ViT on the same uint8 images (ASR_fast.py:90-97 preprocessing)
+    xs = []
+    for i in range(n):
+        pil = Image.fromarray(gen[i].cpu().numpy().transpose(1, 2, 0)).resize((224, 224), Image.BILINEAR)
+        xs.append(torch.from_numpy(np.asarray(pil).transpose(2, 0, 1).astype(np.float32) / 255.0))
+    with torch.no_grad():
+        ref = hf(pixel_values=torch.stack(xs)).logits
+    top2 = ref.topk(2, 1).values
+    margin = top2[:, 0] - top2[:, 1]
+    from advshadow_amd.asr import evaluate_batch
+    pred32 = evaluate_batch(gen, victim("fp32"))
+    assert torch.equal(pred32.cpu().long(), ref.argmax(1))
+    bound16 = 0.01 * max(1.0, ref.abs().max().item())
+    sure = margin > 2 * bound16
+    assert torch.equal(pred.cpu().long()[sure], ref.argmax(1)[sure]), (pred, ref.argmax(1), margin)
+    # fp16 against fp32 along the fp32 trajectory of the same 100-step sequence (teacher forcing: a random-init net
+    # amplifies 16-bit rounding over a free-running loop -- BASELINE.md sec. 2 -- so the bound is per forward)
+    net32, _ = sampler("fp32")
+    trace = []
+    ob.ddim_sample(lambda x, t: net32(x.cuda(), t.cuda()).cpu(), xT, steps=100, trace=trace)
+    assert [tr[0] for tr in trace[:3]] == [991, 981, 971] and trace[-1][0] == 1 and len(trace) == 100
+    worst = 0.0
+    for k in (0, 49, 99):
+        t, eps32, _ = trace[k]
+        x_in = xT if k == 0 else trace[k - 1][2]
+        e16 = net16(x_in.cuda(), torch.full((n,), t, dtype=torch.long, device="cuda")).cpu()
+        worst = max(worst, (e16 - eps32).abs().max().item())
+    print("config-4 reduced: fp16 vs fp32 eps along the 100-step trajectory, max", worst)
+    assert worst < 0.02

@@ -124,3 +124,56 @@ def test_sampler_first_on_a_fresh_engine_does_not_depend_on_allocator_state():
         for _ in range(2):
             got = PLMSDiffusion(sample_steps=4, img_size=64, device="cuda").sample(net, 1, x_T=xT, return_float=True).cpu()
             assert (got - ref).abs().max().item() < 1e-3
+
+
+def test_labels_none_with_cfg_scale_is_unconditional():
+    """ddim.py:77-88 with labels=None: both forwards are model(x, t, None) and lerp(u, u, w) = u, whatever cfg_scale
+    is -- in particular never a conditional forward on the labels a previous call left in the engine."""
+    from advshadow_amd.model.samples.ddpm import DDPMDiffusion
+    from advshadow_amd.model.samples.plms import PLMSDiffusion
+    net = make("silu")
+    g = torch.Generator().manual_seed(21)
+    xT = torch.randn(2, 3, 64, 64, generator=g)
+    diff = DDIMDiffusion(sample_steps=4, img_size=64, device="cuda")
+    diff.sample(net, 2, labels=torch.tensor([3, 30]).cuda(), cfg_scale=3, x_T=xT)      # leaves labels in the engine
+    a = diff.sample(net, 2, labels=None, cfg_scale=3, x_T=xT, return_float=True)
+    b = diff.sample(net, 2, x_T=xT, return_float=True)
+    assert torch.equal(a, b)
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    ref = oa.ddim_sample(lambda x, t, y: oa.unet_forward(sd, x, t, y), xT, labels=None, cfg_scale=3, sample_steps=4,
+                         to_uint8=False)
+    assert (a.cpu() - ref).abs().max().item() < 1e-3
+    p = PLMSDiffusion(sample_steps=4, img_size=64, device="cuda")
+    assert torch.equal(p.sample(net, 2, labels=None, cfg_scale=2, x_T=xT, return_float=True),
+                       p.sample(net, 2, x_T=xT, return_float=True))
+    d = DDPMDiffusion(noise_steps=5, img_size=64, device="cuda")
+    z = {i: torch.randn(2, 3, 64, 64, generator=g) for i in range(2, 5)}
+    assert torch.equal(d.sample(net, 2, labels=None, cfg_scale=2, x_T=xT, noise_fn=lambda i, s: z[i]),
+                       d.sample(net, 2, x_T=xT, noise_fn=lambda i, s: z[i]))
+
+
+def test_forward_at_256_vs_oracle():
+    """SURVEY 8(d) "C1 secondary": UNet(num_classes=37, image_size=256), one classifier-free-guidance pair of forwards
+    (conditional + unconditional) at the headline resolution against the CPU oracle, B = 1, fp32.  This is the shape
+    where attention carries 86 % of the FLOPs: sa6 runs N = 65 536 tokens with d = 16 (attention.py:46-53), sa1/sa5
+    N = 16 384; the oracle evaluates the same row-wise softmax a block of queries at a time (the reference's [4, N, N]
+    weights would be 64 GiB).  Bound: 5e-5 per element (measured 7e-6); bf16 twin: max 0.05, mean 0.008 (measured 0.027 / 0.0044)."""
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    torch.manual_seed(1)
+    net = UNet(num_classes=37, image_size=256, device="cuda").to("cuda").eval()
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    g = torch.Generator().manual_seed(256)
+    x = torch.randn(1, 3, 256, 256, generator=g)
+    t, y = torch.tensor([501]), torch.tensor([17])
+    for yy in (y, None):
+        ref = oa.unet_forward(sd, x, t, yy)
+        for _ in range(2):
+            got = net(x.cuda(), t.cuda(), None if yy is None else yy.cuda()).cpu()
+        err = (got - ref).abs().max().item()
+        print("lineage A 256 fp32", "cond" if yy is not None else "uncond", err)
+        assert err < 5e-5, err
+    torch.manual_seed(1)
+    lp = UNet(num_classes=37, image_size=256, device="cuda", compute_dtype="bf16").to("cuda").eval()
+    e16 = (lp(x.cuda(), t.cuda(), y.cuda()).cpu() - oa.unet_forward(sd, x, t, y)).abs()
+    print("lineage A 256 bf16", e16.max().item(), e16.mean().item())
+    assert e16.max().item() < 0.05 and e16.mean().item() < 0.008

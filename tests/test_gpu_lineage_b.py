@@ -51,8 +51,9 @@ def test_ddim_loop_fp32_vs_golden(golden, tag, sched):
         # 1e-3 per pixel (north_star).  The one exception is the linear schedule on the default
         # net: its first step divides by sqrt(alpha_bar_901) = 1/59, and the REFERENCE ITSELF moves
         # by 3.2e-4 between 1 and 8 CPU threads there (4.3e-4 for a 1e-7 relative nudge of x_T;
-        # measured with the oracle), so that case is held to 3e-3 instead.
-        bound = 3e-3 if (tag, sched) == ("default", "linear") else 1e-3
+        # measured with the oracle).  Measured here: 1.02e-3; held to 1.5e-3 (1e-3 + the reference's own
+        # thread-count noise), not more.
+        bound = 1.5e-3 if (tag, sched) == ("default", "linear") else 1e-3
         assert np.abs(out - ref).max() < bound
 
 
@@ -191,3 +192,56 @@ def test_ddim_fp32_at_256_vs_cpu_oracle():
     ref = ob.ddim_sample(lambda x, tt: ob.unet_forward(sd, hp, x, tt), xT, steps=10)
     out = GaussianDiffusion().ddim_sample(net, 256, batch_size=1, ddim_timesteps=10, x_T=xT, return_tensor=True).cpu()
     assert (out - ref).abs().max().item() < 1e-3
+
+
+_TF256 = {}
+
+
+def _teacher_forced_256():
+    """(x_in, t, oracle eps) at steps 0, 24, 48 of the 50-step sequence, B = 2, 256x256, default net; the trajectory
+    comes from the fp32 HIP path (itself held to 1e-4 per forward against the oracle here).  Cached across dtypes."""
+    if _TF256:
+        return _TF256["cases"]
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    hp = ob.hparams()
+    sd = ob.init_state_dict(0, hp)
+    torch.manual_seed(0)
+    net32 = UNetModel().to("cuda").eval()
+    g = torch.Generator().manual_seed(4321)
+    xT = torch.randn(2, 3, 256, 256, generator=g)
+    trace = []
+    ob.ddim_sample(lambda x, t: net32(x.cuda(), t.cuda()).cpu(), xT, steps=50, trace=trace)
+    assert [tr[0] for tr in trace[:2]] == [981, 961] and trace[-1][0] == 1
+    cases = []
+    for k in (0, 24, 48):                                   # t = 981, 501, 21
+        t, eps32, _ = trace[k]
+        x_in = xT if k == 0 else trace[k - 1][2]
+        ref = ob.unet_forward(sd, hp, x_in, torch.full((2,), t, dtype=torch.long))
+        assert (eps32 - ref).abs().max().item() < 1e-4, t
+        cases.append((x_in, t, ref))
+    _TF256["cases"] = cases
+    del net32
+    torch.cuda.empty_cache()
+    return cases
+
+
+# measured on MI355X (round 2): bf16 max 0.015 / 0.175 / 0.020 at t = 981 / 501 / 21, mean 0.0022-0.0027; fp16 max 0.0024 /
+# 0.0199 / 0.0023, mean 0.00026-0.00034 (the t = 501 maxima are isolated pixels; the means do not move)
+@pytest.mark.parametrize("dt,emax,emean", [("bf16", 0.25, 0.004), ("fp16", 0.03, 0.0005)])
+def test_teacher_forced_16bit_at_256_vs_oracle(dt, emax, emean):
+    """The headline dtype at the headline SHAPE against the oracle: default UNetModel, 2x3x256x256, inputs taken from the
+    fp32 trajectory of the 50-step sequence [981, 961, ..., 1] (teacher forcing: random-init nets amplify 16-bit error
+    over a free-running loop) at an early, a middle and a late step.  Per forward: the fp32 HIP eps
+    within 1e-4 of the CPU oracle, the 16-bit eps within (emax, emean) of it -- every level-0 shape of the halo kernel
+    (M = 65 536 per image, K = 1152 / 2304 / 3456, fused shortcut, sub-pixel upsample) in the dtype the bench runs."""
+    cases = _teacher_forced_256()
+    torch.manual_seed(0)
+    net16 = UNetModel(compute_dtype=dt).to("cuda").eval()
+    worst = []
+    for x_in, t, ref in cases:
+        tt = torch.full((2,), t, dtype=torch.long, device="cuda")
+        for _ in range(2):                                  # second call replays the captured graph
+            err = (net16(x_in.cuda(), tt).cpu() - ref).abs()
+        worst.append((t, round(err.max().item(), 5), round(err.mean().item(), 6)))
+    print("teacher-forced 256", dt, worst)
+    assert all(m < emax and a < emean for _, m, a in worst), worst

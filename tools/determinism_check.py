@@ -51,7 +51,13 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--reps", type=int, default=1, help="reruns of every launch compared with its first run")
+    ap.add_argument("--convs-only", action="store_true")
+    ap.add_argument("--lib", default=None, help="load this build of libadvshadow_hip.so instead of the in-tree one (A/B diagnostics)")
     a = ap.parse_args()
+    if a.lib:
+        from advshadow_amd import _lib
+        _lib.LIB_PATH = os.path.abspath(a.lib)
     torch.manual_seed(0)
     net = UNetModel(compute_dtype=a.dtype, use_graph=False).to("cuda").eval()
     eng = net.engine(a.batch, a.size)
@@ -62,10 +68,13 @@ def main():
     bad = 0
     for i, (fn, args) in enumerate(eng.plan.ops):
         outs = outputs(fn, args, esz)
+        if a.convs_only and fn.__name__ != "advs_conv2d":
+            assert fn(*args, s) == 0
+            continue
         assert fn(*args, s) == 0
         eng.stream.synchronize()
         first = [view(p, n).clone() for p, n in outs]
-        for rep in range(1):
+        for rep in range(a.reps):
             assert fn(*args, s) == 0
             eng.stream.synchronize()
             for k, (p, n) in enumerate(outs):
@@ -80,9 +89,12 @@ def main():
                     if k == 1 and fn.__name__ == "advs_conv2d":
                         c = args[0]._obj
                         f1, f2 = first[k].view(torch.float32).view(-1, c.cout, 2), cur.view(torch.float32).view(-1, c.cout, 2)
-                        idx = (f1 != f2).nonzero()[:6]
-                        for r in idx.tolist():
-                            print("   row-block", r[0], "channel", r[1], "sum/sq", r[2], f1[tuple(r)].item(), f2[tuple(r)].item())
+                        idx = (f1 != f2).nonzero()
+                        print("   entries differing:", idx.shape[0], "sum:", int((idx[:, 2] == 0).sum()), "sumsq:", int((idx[:, 2] == 1).sum()),
+                              "channels mod 8:", sorted(set((idx[:, 1] % 8).tolist())), "row-blocks mod 4:", sorted(set((idx[:, 0] % 4).tolist())))
+                        for r in idx[:8].tolist():
+                            print("   row-block", r[0], "channel", r[1], "sum/sq", r[2], f1[tuple(r)].item(), f2[tuple(r)].item(),
+                                  "delta", f2[tuple(r)].item() - f1[tuple(r)].item())
                     bad += 1
                     break
     print("nondeterministic launches:", bad, "of", len(eng.plan.ops))
