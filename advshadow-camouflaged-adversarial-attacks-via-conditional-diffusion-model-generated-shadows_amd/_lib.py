@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libadvshadow_hip.so")
+# ADVS_LIB_PATH: load another BUILD of the same library (A/B runs of tools/); never a different implementation
+LIB_PATH = os.environ.get("ADVS_LIB_PATH") or os.path.join(_HERE, "libadvshadow_hip.so")
 
 F32, BF16, F16 = 0, 1, 2
 ACT = {"none": 0, None: 0, "relu": 1, "silu": 2, "gelu": 3, "relu6": 4, "lrelu": 5, "lrelu001": 6, "sigmoid": 7}

@@ -30,6 +30,7 @@ struct ConvKP {
     int Ho, Wo, M, K;            // K in elements
     int act, temb_stride;
     int nMt, nNt;
+    int fast_epi;                // 16-bit dtype, no residual / activation / mask: conv_epilogue_fast (bias + temb start in the accumulators)
     FastDiv dHoWo, dWo;
 };
 
@@ -183,6 +184,106 @@ __device__ __forceinline__ void conv_epilogue(const ConvKP& p, f32x16 (&acc)[TM]
             float* sp = p.stats + ((size_t)rb * p.Cout + n) * 2;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) { sp[2 * e] = ssum[e]; sp[2 * e + 1] = ssq[e]; }
+        }
+    }
+}
+
+
+// ---- fast epilogue of the halo kernels for the common case (16-bit storage, no residual, no activation, no mask; every row of the
+// tile inside the image, one image per workgroup).  The generic epilogue above is VALU-bound: ~70 vector instructions per
+// 8-row store, two waves per SIMD, 6.5 us per workgroup at the level-0 shapes = 27 % of those launches (profiles/round2_ablation.txt).
+// Here everything that can be done in the ACCUMULATOR layout (lane = channel, registers = 16 pixel rows) is done there:
+//   * bias and the time-embedding slice are the accumulators' initial value (conv_acc_init), so they cost nothing afterwards;
+//   * rounding packs two pixel rows of one channel per register, and the GroupNorm statistics of the ROUNDED values come from two
+//     v_dot2c per packed pair (sum against a pair of ones, sum of squares against itself), summed over the lane's rows;
+//   * the transposition goes through a 16-bit patch (half the LDS bytes), and the read side is ds_read_b128 -> global_store_dwordx4
+//     with no arithmetic at all.
+template <typename T> __device__ __forceinline__ float dot2_acc(unsigned a, unsigned b, float c);
+template <> __device__ __forceinline__ float dot2_acc<BF16>(unsigned a, unsigned b, float c) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, a), __builtin_bit_cast(bf2, b), c, false);
+}
+template <> __device__ __forceinline__ float dot2_acc<F16>(unsigned a, unsigned b, float c) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, a), __builtin_bit_cast(h2, b), c, false);
+}
+template <> __device__ __forceinline__ float dot2_acc<float>(unsigned, unsigned, float c) { return c; }   // never used (fast_epi is 16-bit only)
+template <typename T> __device__ __forceinline__ unsigned ones_pair() { return 0x3c003c00u; }          // (1.0, 1.0) in fp16
+template <> __device__ __forceinline__ unsigned ones_pair<BF16>() { return 0x3f803f80u; }
+
+// Accumulator start value: zero, or -- for the fast epilogue -- bias (+ the image's time-embedding slice) of the lane's channel.
+// (Tried and dropped: also starting from the residual, gathered in the accumulator layout with 64 two-byte loads per lane in front
+// of the prologue -- 853 us against 825 us for the generic epilogue at the level-0 shape; the residual layers keep the generic path.)
+template <int TM, int TN>
+__device__ __forceinline__ void conv_acc_init(const ConvKP& p, f32x16 (&acc)[TM][TN], int lane, int ncol0, int temb_b) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int c = ncol0 + j * 32 + (lane & 31);
+        float v = 0.f;
+        if (p.fast_epi && c < p.Cout) {
+            if (p.bias) v = p.bias[c];
+            if (p.temb) v += p.temb[(size_t)temb_b * p.temb_stride + c];
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = v;
+    }
+}
+
+template <typename T, int WN, int TM, int TN, typename RowMap>
+__device__ __forceinline__ void conv_epilogue_fast(const ConvKP& p, f32x16 (&acc)[TM][TN], char* patch, int lane, int ncol0,
+                                                   RowMap row_to_m, int rb) {
+    static_assert(WN == TN * 32, "one wave owns TN channel tiles");
+    constexpr int ROWB = WN * 2;                  // bytes of one patch row (16-bit elements)
+    constexpr int LPR = ROWB / 16, RPI = 64 / LPR;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int prow = lane / LPR, pcv = lane - prow * LPR;
+    const int n = ncol0 + pcv * 8;
+    const bool n_ok = n < p.Cout;
+    const unsigned ones = ones_pair<T>();
+    char* y = p.y;
+    float ssum[TN], ssq[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int r = 2 * q;                                 // registers r, r + 1 = pixel rows row, row + 1
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const unsigned pk = pack2<T>(acc[i][j][r], acc[i][j][r + 1]);
+                ssum[j] = dot2_acc<T>(pk, ones, ssum[j]);
+                ssq[j] = dot2_acc<T>(pk, pk, ssq[j]);
+                unsigned short* dst = (unsigned short*)(patch + row * ROWB + (j * 32 + l31) * 2);
+                dst[0] = (unsigned short)pk;
+                dst[ROWB / 2] = (unsigned short)(pk >> 16);
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int it = 0; it < 32 / RPI; ++it) {
+            const int row = it * RPI + prow;
+            const int m = row_to_m(i * 32 + row);
+            const u32x4 v = *(const u32x4*)(patch + row * ROWB + pcv * 16);
+            if (m >= 0 && n_ok) *(u32x4*)(y + ((size_t)m * p.Cout + n) * 2) = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (p.stats && rb >= 0) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {                               // the two lane halves hold the other 16 rows of the same channel
+            const float s = ssum[j] + __shfl_xor(ssum[j], 32), q = ssq[j] + __shfl_xor(ssq[j], 32);
+            const int c = ncol0 + j * 32 + l31;
+            if (lh == 0 && c < p.Cout) {
+                float2* sp = (float2*)(p.stats + ((size_t)rb * p.Cout + c) * 2);
+                *sp = make_float2(s, q);
+            }
         }
     }
 }

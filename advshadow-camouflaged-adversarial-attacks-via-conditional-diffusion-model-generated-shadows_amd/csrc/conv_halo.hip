@@ -86,6 +86,7 @@ conv3x3_halo_kernel(const ConvKP p) {
     const int b = tl / tpi, ti = tl - b * tpi;
     const int ty = ti / tiles_x, tx = ti - ty * tiles_x;
     const int y0 = ty * HT, x0 = tx * HT, n0 = nt * 128;
+    const int wr = wave >> 1, wc = wave & 1;
 
     // ---- staging geometry.  Halo piece q covers halo pixels 8q .. 8q+7 (row-major in the 18x18 patch).
     int apix[HNP];                                   // source pixel index, -1 = outside the image / patch
@@ -151,7 +152,6 @@ conv3x3_halo_kernel(const ConvKP p) {
     };
 
     // ---- fragment geometry: wave (wr, wc) owns tile rows 4wr..4wr+3 (x16 px) and channels wc*64..+63
-    const int wr = wave >> 1, wc = wave & 1;
     int hidx0[2], b_off[2], b_sw[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -162,13 +162,13 @@ conv3x3_halo_kernel(const ConvKP p) {
         b_off[i] = rb * SLAB; b_sw[i] = (rb >> 1) & 7;
     }
 
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto row_to_m = [&](int lr) {
+        int g, idx;
+        halo_row_map(lr & 31, g, idx);
+        const int yy = y0 + 4 * wr + 2 * (lr >> 5) + g, xx = x0 + idx;      // input-grid pixel
+        if (NT == 9) return (b * p.H + yy) * p.W + xx;
+        return (b * 2 * p.H + 2 * yy + r0) * (2 * p.W) + 2 * xx + s0;       // its parity's output
+    };
 
     // ---- prologue: halo of slab 0, weights of taps 0, 1 and 2
     set_a_voff(0);
@@ -177,6 +177,9 @@ conv3x3_halo_kernel(const ConvKP p) {
     issue_B(0, 0, 0); issue_B(0, 0, 1);
     issue_B(0, 1, 0); issue_B(0, 1, 1);
     issue_B(0, 2, 0); issue_B(0, 2, 1);
+
+    f32x16 acc[2][2];                                // zero, or (fast epilogue) bias + time embedding
+    conv_acc_init<2, 2>(p, acc, lane, n0 + wc * 64, b);
 
     u32x4 af[2][2], bf[2][2];                        // [k-step parity][tile]; slot 0 is carried across taps
     auto load_frags = [&](int slot, const char* la, const char* lb, int r, int s, int ks) {
@@ -274,14 +277,13 @@ conv3x3_halo_kernel(const ConvKP p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                    // every wave is done reading before the patches reuse LDS
 
-    conv_epilogue<T, 64, 2, 2>(p, acc, (float*)smem + wave * (32 * 64), lane, n0 + wc * 64,
-                               [&](int lr) {
-                                   int g, idx;
-                                   halo_row_map(lr & 31, g, idx);
-                                   const int yy = y0 + 4 * wr + 2 * (lr >> 5) + g, xx = x0 + idx;      // input-grid pixel
-                                   if (NT == 9) return (b * p.H + yy) * p.W + xx;
-                                   return (b * 2 * p.H + 2 * yy + r0) * (2 * p.W) + 2 * xx + s0;       // its parity's output
-                               },
+    if constexpr (sizeof(T) == 2) {
+        if (p.fast_epi) {
+            conv_epilogue_fast<T, 64, 2, 2>(p, acc, smem + wave * (32 * 64 * 2), lane, n0 + wc * 64, row_to_m, (tl * NPAR + par) * 4 + wr);
+            return;
+        }
+    }
+    conv_epilogue<T, 64, 2, 2>(p, acc, (float*)smem + wave * (32 * 64), lane, n0 + wc * 64, row_to_m,
                                p.temb ? b : -1, (tl * NPAR + par) * 4 + wr);
 }
 

@@ -398,6 +398,7 @@ extern "C" int advs_conv2d(const advs_conv_args* a, void* stream) {
     p.x1 = (const char*)a->x1; p.x2 = (const char*)a->x2; p.w = (const char*)a->w;
     p.bias = a->bias; p.temb = a->temb; p.res = (const char*)a->residual; p.y = (char*)a->y;
     p.stats = a->stats;
+    p.fast_epi = 0;
     p.mask = (const char*)a->relu_mask;
     ADVS_REQUIRE(!a->relu_mask || (!a->stats && a->upsample != ADVS_UPSAMPLE_SUBPIXEL && (a->tile == 0 || a->tile == 1 || a->tile == 4)),
                  "conv2d: relu_mask needs a per-tap tile (0, 1 or 4), no stats, no sub-pixel upsample");
@@ -444,6 +445,9 @@ extern "C" int advs_conv2d(const advs_conv_args* a, void* stream) {
         if (g_tile_override && a->stats_rows != wm) p.stats = nullptr;   // tuning runs: buffer sized for another tile
         else ADVS_REQUIRE(a->stats_rows == wm, "conv2d: stats buffer sized for %d-row blocks but the tile uses %d", a->stats_rows, wm);
     }
+    // the halo kernels' fast epilogue (conv_common.h): 16-bit storage, nothing but bias / time embedding / statistics around the GEMM
+    p.fast_epi = (tile == 10 || tile == 12 || tile == 13) && a->dtype != ADVS_F32 && !a->residual && !a->relu_mask &&
+                 a->act == ADVS_ACT_NONE && getenv("ADVS_NO_FAST_EPILOGUE") == nullptr;
     if (tile == 12) return conv_halo_subpixel_dispatch(p, a->dtype, (hipStream_t)stream);
     if (tile == 13) return conv_halo_extra_dispatch(p, a->dtype, (hipStream_t)stream);
     if (tile == 10) return conv_halo_dispatch(p, a->dtype, (hipStream_t)stream);
