@@ -72,6 +72,8 @@ SIGNATURES = {
     "advs_apply_shadow_parts": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, C.POINTER(f32), i32, vp],
     "advs_blend_mask_clamp01": [vp, vp, vp, vp, C.c_longlong, vp],
     "advs_composite_u8": [vp, vp, vp, vp, sz, i32, f32, vp],
+    "advs_composite_u8_masks": [vp, vp, vp, vp, i32, vp, sz, i32, f32, vp],
+    "advs_mask_contours": [vp, i32, i32, i32, vp, vp, vp, i32, vp],
     "advs_resample_u8": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "advs_u8hwc_to_f32nchw": [vp, vp, i32, i32, i32, i32, vp, vp, vp],
     "advs_u8_nchw_to_hwc": [vp, vp, i32, i32, i32, i32, vp],
@@ -103,8 +105,10 @@ SIGNATURES = {
     "advs_event_destroy": [vp],
     "advs_stream_sync": [vp],
 }
-_RESTYPES = {"advs_last_error": C.c_char_p, "advs_groupnorm_scratch_bytes": sz, "advs_jpeg_scratch_bytes": sz}
-_EXTRA = {"advs_last_error": [], "advs_groupnorm_scratch_bytes": [i32, i32], "advs_jpeg_scratch_bytes": [i32, i32, i32]}
+_RESTYPES = {"advs_last_error": C.c_char_p, "advs_groupnorm_scratch_bytes": sz, "advs_jpeg_scratch_bytes": sz,
+             "advs_mask_contours_work_bytes": sz}
+_EXTRA = {"advs_last_error": [], "advs_groupnorm_scratch_bytes": [i32, i32], "advs_jpeg_scratch_bytes": [i32, i32, i32],
+          "advs_mask_contours_work_bytes": [i32, i32, i32]}
 
 _lib = None
 

@@ -130,17 +130,18 @@ __device__ __forceinline__ void alpha_composite_px(const unsigned* dst, const un
     for (int c = 0; c < 3; ++c) out[c] = shiftdiv255(src[c] * coef1 + dst[c] * coef2 + (0x80u << 7)) >> 7;
 }
 
-// mode 0 (add_shadow.py:57-58): out = Image.composite(alpha_composite(img, layer), img, mask)
+// mode 0 (add_shadow.py:57-58): out = Image.composite(alpha_composite(img, layer), img, pmask)
 // mode 1 (shadow_for_attack.py:76-93): the layer is first pasted onto (255,255,255,0) through
-//   L(layer) & mask, alpha-composited, then every channel of mask!=0 pixels is scaled by `factor`
-//   in float32, clipped to [0,255] and truncated (shadow_for_attack.py:50-73).
+//   L(layer) & pmask, alpha-composited, then every ELEMENT whose darkening mask is nonzero (dmask: one value per pixel, or one
+//   per channel when the mask image has three) is scaled by `factor` in float32, clipped to [0,255] and truncated
+//   (shadow_for_attack.py:50-73).  layer / pmask are already on the image's grid (the host pastes at (0,0) as Pillow does).
 __global__ void composite_u8_kernel(const uint8_t* __restrict__ img, const uint8_t* __restrict__ layer,
-                                    const uint8_t* __restrict__ mask, uint8_t* __restrict__ out, size_t npix,
-                                    int mode, float factor) {
+                                    const uint8_t* __restrict__ pmask, const uint8_t* __restrict__ dmask, int dch,
+                                    uint8_t* __restrict__ out, size_t npix, int mode, float factor) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < npix; i += (size_t)gridDim.x * blockDim.x) {
         unsigned d[3] = {img[3 * i], img[3 * i + 1], img[3 * i + 2]};
         unsigned s[4] = {layer[4 * i], layer[4 * i + 1], layer[4 * i + 2], layer[4 * i + 3]};
-        const unsigned m = mask[i];
+        const unsigned m = pmask[i];
         unsigned o[3];
         if (mode == 0) {
             unsigned c[3];
@@ -156,9 +157,9 @@ __global__ void composite_u8_kernel(const uint8_t* __restrict__ img, const uint8
 #pragma unroll
             for (int k = 0; k < 4; ++k) ly[k] = blend8(pm, base[k], s[k]);
             alpha_composite_px(d, ly, o);
-            if (m != 0) {
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
+            for (int k = 0; k < 3; ++k) {
+                if (dmask[dch == 1 ? i : 3 * i + k] != 0) {
                     float f = (float)o[k] * factor;
                     f = fminf(fmaxf(f, 0.f), 255.f);
                     o[k] = (unsigned)f;
@@ -169,14 +170,21 @@ __global__ void composite_u8_kernel(const uint8_t* __restrict__ img, const uint8
     }
 }
 
-extern "C" int advs_composite_u8(const uint8_t* img_hwc, const uint8_t* layer_rgba, const uint8_t* mask,
-                                 uint8_t* out_hwc, size_t npix, int mode, float factor, void* stream) {
-    ADVS_REQUIRE(img_hwc && layer_rgba && mask && out_hwc && npix > 0, "composite_u8: bad args");
+extern "C" int advs_composite_u8_masks(const uint8_t* img_hwc, const uint8_t* layer_rgba, const uint8_t* paste_mask,
+                                       const uint8_t* dark_mask, int dark_channels, uint8_t* out_hwc, size_t npix, int mode,
+                                       float factor, void* stream) {
+    ADVS_REQUIRE(img_hwc && layer_rgba && paste_mask && dark_mask && out_hwc && npix > 0, "composite_u8: bad args");
     ADVS_REQUIRE(mode == 0 || mode == 1, "composite_u8: mode %d unknown", mode);
+    ADVS_REQUIRE(dark_channels == 1 || dark_channels == 3, "composite_u8: the darkening mask has 1 or 3 channels, not %d", dark_channels);
     const int grid = (int)((npix + 255) / 256 < 4096 ? (npix + 255) / 256 : 4096);
-    composite_u8_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(img_hwc, layer_rgba, mask, out_hwc, npix, mode, factor);
+    composite_u8_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(img_hwc, layer_rgba, paste_mask, dark_mask, dark_channels, out_hwc,
+                                                              npix, mode, factor);
     ADVS_CHECK_LAUNCH("composite_u8");
     return ADVS_OK;
+}
+extern "C" int advs_composite_u8(const uint8_t* img_hwc, const uint8_t* layer_rgba, const uint8_t* mask,
+                                 uint8_t* out_hwc, size_t npix, int mode, float factor, void* stream) {
+    return advs_composite_u8_masks(img_hwc, layer_rgba, mask, mask, 1, out_hwc, npix, mode, factor, stream);
 }
 
 // ============================================================================ PIL resize (uint8, 2 passes)

@@ -80,77 +80,130 @@ def create_shadow_mask(image_size, shadow_center, shadow_radius, device="cpu"):
     return (d <= shadow_radius).float()
 
 
+# --------------------------------------------------------------------------- contours (cv2.findContours stand-in)
+MAX_CONTOURS = 4096
+
+
+def cv_gray(mask):
+    """``np.array(mask)`` + ``cv2.cvtColor(RGB2GRAY)`` for 3-channel masks (add_shadow.py:36-38, shadow_for_attack.py:26-28):
+    OpenCV's 8-bit fixed point (R*4899 + G*9617 + B*1868 + 8192) >> 14, which is NOT Pillow's ``convert('L')``."""
+    a = np.asarray(mask)
+    if a.dtype == np.bool_:
+        a = a.astype(np.uint8) * 255
+    if a.ndim == 3:
+        r, g, b = (a[..., k].astype(np.int32) for k in range(3))
+        a = ((r * 4899 + g * 9617 + b * 1868 + 8192) >> 14).astype(np.uint8)
+    return np.ascontiguousarray(a.astype(np.uint8))
+
+
+def external_contours_batch(masks_u8):
+    """``cv2.findContours(mask, RETR_EXTERNAL, CHAIN_APPROX_SIMPLE)`` for a batch of masks, on the device
+    (``advs_mask_contours``): masks_u8 uint8 [n, H, W] on the GPU (nonzero = foreground) -> per mask the list of
+    ``(x, y, w, h, 2 * contourArea, first_pixel)`` -- ``cv2.boundingRect`` and twice ``cv2.contourArea`` of every external
+    contour -- in OpenCV's list order (the reverse of the raster order in which the border following meets them)."""
+    _lib.init_device()
+    lib = _lib.load()
+    m = masks_u8.contiguous()
+    n, H, W = m.shape
+    dev = m.device
+    work = torch.empty(lib.advs_mask_contours_work_bytes(n, H, W), dtype=torch.uint8, device=dev)
+    out = torch.empty((n, MAX_CONTOURS, 8), dtype=torch.int32, device=dev)
+    cnt = torch.empty((n,), dtype=torch.int32, device=dev)
+    check(lib.advs_mask_contours(m.data_ptr(), n, H, W, work.data_ptr(), out.data_ptr(), cnt.data_ptr(), MAX_CONTOURS,
+                                 torch.cuda.current_stream(dev).cuda_stream), "mask_contours")
+    cnt_h = cnt.cpu().tolist()
+    res = []
+    for i, c in enumerate(cnt_h):
+        if c > MAX_CONTOURS:
+            raise _lib.AdvsError(f"mask {i} has {c} external contours (limit {MAX_CONTOURS})")
+        rows = out[i, :c].cpu().tolist()
+        rows.sort(key=lambda e: -e[0])                       # last found first
+        res.append([(e[1], e[2], e[3] - e[1] + 1, e[4] - e[2] + 1, e[6], e[0]) for e in rows])
+    return res
+
+
+def external_contours(mask):
+    """One PIL mask -> its external contours (see external_contours_batch)."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
+    if dev is None:
+        raise _lib.AdvsError("no GPU visible: the AdvShadow HIP path needs an MI355X (there is no CPU fallback)")
+    return external_contours_batch(torch.from_numpy(cv_gray(mask)).to(dev)[None])[0]
+
+
+def cv_resize_nearest(a, width, height):
+    """``cv2.resize(a, (width, height), interpolation=cv2.INTER_NEAREST)``: source index floor(dst * src / dst_size), clipped
+    (not Pillow's centre-aligned NEAREST)."""
+    sh, sw = a.shape[:2]
+    ys = np.minimum(np.floor(np.arange(height) * (sh / height)).astype(np.int64), sh - 1)
+    xs = np.minimum(np.floor(np.arange(width) * (sw / width)).astype(np.int64), sw - 1)
+    return a[ys][:, xs]
+
+
 # --------------------------------------------------------------------------- PIL composites
-def mask_blobs(mask_l):
-    """Bounding boxes (x, y, w, h, area) of the 8-connected foreground blobs of an L-mode mask: the
-    host stand-in for cv2.findContours(EXTERNAL) + boundingRect (cv2 is not a dependency here)."""
-    m = np.asarray(mask_l) != 0
-    H, W = m.shape
-    lab = np.zeros((H, W), dtype=np.int32)
-    boxes = []
-    for y0, x0 in zip(*np.nonzero(m)):
-        if lab[y0, x0]:
-            continue
-        idx = len(boxes) + 1
-        stack = [(y0, x0)]
-        lab[y0, x0] = idx
-        xs0, xs1, ys0, ys1, area = x0, x0, y0, y0, 0
-        while stack:
-            y, x = stack.pop()
-            area += 1
-            xs0, xs1, ys0, ys1 = min(xs0, x), max(xs1, x), min(ys0, y), max(ys1, y)
-            for dy in (-1, 0, 1):
-                for dx in (-1, 0, 1):
-                    yy, xx = y + dy, x + dx
-                    if 0 <= yy < H and 0 <= xx < W and m[yy, xx] and not lab[yy, xx]:
-                        lab[yy, xx] = idx
-                        stack.append((yy, xx))
-        boxes.append((int(xs0), int(ys0), int(xs1 - xs0 + 1), int(ys1 - ys0 + 1), area))
-    return boxes
-
-
 def _triangle_layer(size, cx, cy, t):
     layer = Image.new("RGBA", size, (255, 255, 255, 0))
     ImageDraw.Draw(layer).polygon([(cx, cy - t), (cx - t, cy + t), (cx + t, cy + t)], fill=(0, 0, 0, 128))
     return layer
 
 
-def _composite(image_rgb, layer, mask_l, mode, factor=0.43):
+def _composite(image_rgb, layer, paste_mask, dark_mask, mode, factor=0.43):
+    """image RGB, layer RGBA and the two masks all at the image's size (dark_mask [H,W] or [H,W,3]; mode 0 uses paste_mask
+    only)."""
     _lib.init_device()
     dev = torch.device("cuda", torch.cuda.current_device())
-    img = torch.from_numpy(np.asarray(image_rgb, dtype=np.uint8).copy()).to(dev)
-    lay = torch.from_numpy(np.asarray(layer, dtype=np.uint8).copy()).to(dev)
-    msk = torch.from_numpy(np.asarray(mask_l, dtype=np.uint8).copy()).to(dev)
+    img_np = np.asarray(image_rgb, dtype=np.uint8)
+    lay_np, pm_np, dm_np = (np.ascontiguousarray(np.asarray(a, dtype=np.uint8)) for a in (layer, paste_mask, dark_mask))
+    H, W = img_np.shape[:2]
+    if lay_np.shape != (H, W, 4) or pm_np.shape != (H, W) or dm_np.shape[:2] != (H, W) or dm_np.ndim not in (2, 3):
+        raise ValueError(f"composite: layer {lay_np.shape}, masks {pm_np.shape} / {dm_np.shape} do not match the image {img_np.shape}")
+    dch = 1 if dm_np.ndim == 2 else dm_np.shape[2]
+    if dch not in (1, 3):
+        raise ValueError(f"composite: a mask with {dch} channels cannot index an RGB image (shadow_for_attack.py:62-65)")
+    img, lay, pm, dm = (torch.from_numpy(a.copy()).to(dev) for a in (img_np, lay_np, pm_np, dm_np))
     out = torch.empty_like(img)
     s = torch.cuda.current_stream(dev).cuda_stream
-    check(_lib.load().advs_composite_u8(img.data_ptr(), lay.data_ptr(), msk.data_ptr(), out.data_ptr(),
-                                        img.shape[0] * img.shape[1], mode, float(factor), s), "composite_u8")
+    check(_lib.load().advs_composite_u8_masks(img.data_ptr(), lay.data_ptr(), pm.data_ptr(), dm.data_ptr(), dch, out.data_ptr(),
+                                              H * W, mode, float(factor), s), "composite_u8")
     return Image.fromarray(out.cpu().numpy())
 
 
 def add_shadow(image, mask):
-    """add_shadow.py:35-60: PIL RGB image + mask -> PIL RGB image with the triangle shadow."""
+    """add_shadow.py:35-60: PIL RGB image + mask -> PIL RGB image with the triangle shadow in the bounding box of the external
+    contour of largest ``cv2.contourArea`` (first one in OpenCV's list order on ties, as Python's ``max`` picks)."""
     image = image.convert("RGB")
-    mask_l = mask.convert("L")
-    boxes = mask_blobs(mask_l)
-    if not boxes:
+    if mask.size != image.size:
+        raise ValueError("images do not match")              # Image.composite's own error (add_shadow.py:58)
+    contours = external_contours(mask)
+    if not contours:
         raise ValueError("mask has no foreground (add_shadow.py:44 would fail on max() of no contours)")
-    x, y, w, h, _ = max(boxes, key=lambda b: b[4])
+    x, y, w, h = max(contours, key=lambda c: c[4])[:4]
     cx, cy, t = x + w // 2, y + h // 2, min(w, h) // 2
-    return _composite(image, _triangle_layer(image.size, cx, cy, t), mask_l, 0)
+    mask_l = np.asarray(mask.convert("L"))
+    return _composite(image, _triangle_layer(image.size, cx, cy, t), mask_l, mask_l, 0)
 
 
 def add_shadow_to_mask_area(image, mask, rng=random):
-    """shadow_for_attack.py:22-93 (triangle in the centre part of a randomly chosen blob, then the
-    0.43 darkening of every masked pixel)."""
-    mask_l = mask.convert("L")
-    boxes = mask_blobs(mask_l)
-    if not boxes:
+    """shadow_for_attack.py:22-93: triangle in the centre part of ``random.choice(contours)``, pasted through
+    ``L(layer) & L(mask)``, then every mask-true element scaled by 0.43.  The mask may differ from the image in size: the
+    triangle layer and the paste mask live on the mask's grid and are pasted at (0, 0), cropped or padded as Pillow's
+    ``paste`` does; the darkening mask is ``cv2.resize(..., INTER_NEAREST)`` of ``np.array(mask)``, per channel when the
+    mask has three (shadow_for_attack.py:50-71)."""
+    contours = external_contours(mask)
+    if not contours:
         return image
-    x, y, w, h, _ = rng.choice(boxes)
+    x, y, w, h = rng.choice(contours)[:4]
     sx, sy, sw, sh = x + w // 4, y + h // 4, w // 2, h // 2
     cx, cy, t = sx + sw // 2, sy + sh // 2, min(sw, sh) // 3
-    layer = _triangle_layer(mask.size, cx, cy, t)
-    if mask_l.size != image.size:
-        mask_l = mask_l.resize(image.size, Image.NEAREST)     # cv2.resize(..., INTER_NEAREST) in the reference
-    return _composite(image.convert("RGB"), layer, mask_l, 1, 0.43)
+    tri = np.asarray(_triangle_layer(mask.size, cx, cy, t))
+    W, H = image.size
+    layer = np.empty((H, W, 4), dtype=np.uint8)
+    layer[...] = (255, 255, 255, 0)
+    paste = np.zeros((H, W), dtype=np.uint8)
+    hh, ww = min(H, tri.shape[0]), min(W, tri.shape[1])
+    layer[:hh, :ww] = tri[:hh, :ww]
+    paste[:hh, :ww] = np.asarray(mask.convert("L"))[:hh, :ww]
+    m = np.asarray(mask)
+    if m.dtype == np.bool_:
+        m = m.astype(np.uint8)
+    dark = cv_resize_nearest(m, W, H) if (m.shape[1], m.shape[0]) != (W, H) else m
+    return _composite(image.convert("RGB"), layer, paste, dark, 1, 0.43)

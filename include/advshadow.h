@@ -248,6 +248,20 @@ int advs_blend_mask_clamp01(const float* img, const float* adv, const float* cma
  * mode 1: add_shadow_to_mask_area + adjust_shadow_brightness(factor)  (shadow_for_attack.py:50-93) */
 int advs_composite_u8(const uint8_t* img_hwc, const uint8_t* layer_rgba, const uint8_t* mask,
                       uint8_t* out_hwc, size_t npix, int mode, float factor, void* stream);
+/* The same with the two roles of the mask apart (shadow_for_attack.py:76-93 when mask.size != image.size): paste_mask [npix]
+ * gates the layer (L(layer) & paste_mask, or the composite's blend in mode 0), dark_mask [npix][dark_channels] (1 or 3) selects
+ * the elements scaled by `factor` -- np.array(mask) after cv2.resize(INTER_NEAREST), per channel for a 3-channel mask.      */
+int advs_composite_u8_masks(const uint8_t* img_hwc, const uint8_t* layer_rgba, const uint8_t* paste_mask,
+                            const uint8_t* dark_mask, int dark_channels, uint8_t* out_hwc, size_t npix, int mode,
+                            float factor, void* stream);
+/* cv2.findContours(mask, RETR_EXTERNAL, CHAIN_APPROX_SIMPLE) + boundingRect + contourArea for n masks [n][h][w] (nonzero =
+ * foreground; add_shadow.py:40-47, shadow_for_attack.py:30-35), without border following: out[i][k][8] = {first pixel in
+ * raster order, min x, min y, max x, max y, pixels of the hole-filled component, 2 * contourArea, 0} for the k-th external
+ * contour found (any order; sort by the first pixel), count[i] = how many (may exceed max_components: then only that many rows
+ * were written).  work: advs_mask_contours_work_bytes(n, h, w) bytes of scratch.                                              */
+size_t advs_mask_contours_work_bytes(int n, int h, int w);
+int advs_mask_contours(const uint8_t* mask, int n, int h, int w, void* work, int* out, int* count, int max_components,
+                       void* stream);
 /* One pass of Pillow's 8-bit ImagingResample (Image.resize behind transforms.Resize, ASR_fast.py:93,
  * PSNR_SSIM_fast.py:11): bounds[o] = {first input index, tap count}, coefs[o][ksize] int32 fixed
  * point (22 bits), computed by the host as Pillow does.  Images [n][h][w][channels] uint8.        */

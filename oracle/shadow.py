@@ -77,3 +77,47 @@ def add_shadow_to_mask_area_with_bbox(image, mask, bbox):
     layer.paste(tri, mask=inter)
     combined = Image.alpha_composite(image.convert("RGBA"), layer).convert("RGB")
     return adjust_shadow_brightness(combined, mask.convert("L"))
+
+
+# --------------------------------------------------------------------------- the two scripts end to end (contours included)
+def cv_resize_nearest(a, width, height):
+    """``cv2.resize(a, (width, height), interpolation=cv2.INTER_NEAREST)`` restated: src = min(floor(dst * scale), size - 1)."""
+    sh, sw = a.shape[:2]
+    ys = np.minimum(np.floor(np.arange(height) * (sh / height)).astype(np.int64), sh - 1)
+    xs = np.minimum(np.floor(np.arange(width) * (sw / width)).astype(np.int64), sw - 1)
+    return a[ys][:, xs]
+
+
+def add_shadow(original_image, mask_image):
+    """add_shadow.py:35-58: largest external contour by ``contourArea`` (first maximum in OpenCV's list order)."""
+    from . import contours as oc
+    cs = oc.external_contours(oc.cv_gray(mask_image))
+    best = max(cs, key=lambda c: c[4])
+    return add_shadow_with_bbox(original_image, mask_image.convert("L"), best[:4])
+
+
+def add_shadow_to_mask_area(image, mask, rng):
+    """shadow_for_attack.py:22-93 with Pillow doing the integer work: ``rng.choice(contours)``; the triangle layer and
+    the paste mask live at mask.size and are pasted at (0, 0) (Pillow crops / leaves the rest); the darkening mask is
+    ``np.array(mask)`` after cv2's nearest resize, indexing per element (so per channel for an RGB mask)."""
+    from . import contours as oc
+    cs = oc.external_contours(oc.cv_gray(mask))
+    if not cs:
+        return image
+    x, y, w, h = rng.choice(cs)[:4]
+    sx, sy, sw, sh = x + w // 4, y + h // 4, w // 2, h // 2
+    cx, cy = sx + sw // 2, sy + sh // 2
+    tri = triangle_layer(mask.size, cx, cy, min(sw, sh) // 3)
+    inter = Image.fromarray(np.bitwise_and(np.array(tri.convert("L")), np.array(mask.convert("L"))))
+    layer = Image.new("RGBA", image.size, (255, 255, 255, 0))
+    layer.paste(tri, mask=inter)
+    combined = Image.alpha_composite(image.convert("RGBA"), layer).convert("RGB")
+    image_np = np.array(combined)
+    mask_np = np.array(mask)
+    if mask_np.dtype == np.bool_:
+        mask_np = mask_np.astype(np.uint8)
+    mask_np = cv_resize_nearest(mask_np, image_np.shape[1], image_np.shape[0])
+    fl = image_np.astype(np.float32)
+    fl[mask_np.astype(bool)] *= 0.43
+    np.clip(fl, 0, 255, out=fl)
+    return Image.fromarray(fl.astype(np.uint8))

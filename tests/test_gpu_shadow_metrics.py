@@ -22,26 +22,97 @@ def synth(h, w, seed):
     return img, Image.fromarray(m), Image.fromarray(soft.astype(np.uint8))
 
 
+def contour_masks():
+    """Masks that separate the contour rules: holes (contourArea counts them, a pixel count does not), a blob nested in a
+    hole (not an external contour), one-pixel bridges, blobs on the frame, specks, equal-area ties."""
+    ms = {}
+    yy, xx = np.mgrid[0:96, 0:128]
+    ring = (((xx - 40) ** 2 + (yy - 48) ** 2 <= 30 ** 2) & ((xx - 40) ** 2 + (yy - 48) ** 2 > 22 ** 2))
+    disc = (xx - 98) ** 2 + (yy - 30) ** 2 <= 24 ** 2                       # more pixels than the ring, smaller contourArea
+    nested = (xx - 40) ** 2 + (yy - 48) ** 2 <= 6 ** 2
+    ms["ring_vs_disc"] = ring | disc | nested
+    m = np.zeros((64, 80), bool)
+    m[5:20, 5:20] = True; m[19:21, 19:21] = True; m[20:40, 20:45] = True     # two squares joined by a diagonal bridge
+    m[0:6, 70:80] = True; m[58:64, 0:9] = True                               # on the frame
+    m[50, 50] = True; m[30, 60:63] = True                                    # specks
+    ms["bridges"] = m
+    m = np.zeros((40, 40), bool)
+    m[3:13, 3:13] = True; m[20:30, 22:32] = True                             # equal areas: the tie goes to the LAST one found
+    ms["tie"] = m
+    rng = np.random.default_rng(5)
+    ms["noise"] = rng.random((72, 90)) < 0.55
+    return {k: (v.astype(np.uint8) * 255) for k, v in ms.items()}
+
+
+@pytest.mark.parametrize("name", ["ring_vs_disc", "bridges", "tie", "noise"])
+def test_external_contours_vs_suzuki_oracle_and_scipy(name):
+    """advs_mask_contours (flood + labelling + 2x2-cell area, no border following) against the Suzuki-Abe restatement
+    (oracle/contours.py: border following, Green's formula) -- boxes, twice the contourArea, first pixels and list order --
+    and the boxes against scipy.ndimage (fill holes, label with 8-connectivity), an implementation neither shares."""
+    from scipy import ndimage as ndi
+    from oracle import contours as oc
+    m = contour_masks()[name]
+    got = shadow.external_contours(Image.fromarray(m))
+    assert got == [tuple(int(v) for v in c) for c in oc.external_contours(m)]
+    lab, n = ndi.label(ndi.binary_fill_holes(m != 0), structure=np.ones((3, 3)))
+    boxes = sorted((sl[1].start, sl[0].start, sl[1].stop - sl[1].start, sl[0].stop - sl[0].start) for sl in ndi.find_objects(lab))
+    assert sorted(c[:4] for c in got) == boxes and len(got) == n
+    if name == "ring_vs_disc":                          # the ring wins by contourArea although the disc has more pixels
+        best = max(got, key=lambda c: c[4])
+        assert best[:4] == (10, 18, 61, 61) and (m[18:79, 10:71] != 0).sum() < (m[6:55, 74:123] != 0).sum()
+    batch = shadow.external_contours_batch(torch.from_numpy(np.stack([m, np.zeros_like(m), m[::-1].copy()])).cuda())
+    assert batch[0] == got and batch[1] == [] and len(batch[2]) == len(got)
+
+
 @pytest.mark.parametrize("size", [(64, 64), (97, 131), (256, 256)])
 def test_add_shadow_bit_exact_vs_pillow(size):
     img, hard, soft = synth(*size, seed=1)
     for mask in (hard, soft):                             # soft mask exercises the fractional BLEND8 path
-        boxes = shadow.mask_blobs(mask.convert("L"))
-        bbox = max(boxes, key=lambda b: b[4])[:4]
-        ref = osh.add_shadow_with_bbox(img, mask, bbox)
+        ref = osh.add_shadow(img, mask)
         got = shadow.add_shadow(img, mask)
         assert got.mode == "RGB" and np.array_equal(np.asarray(got), np.asarray(ref.convert("RGB")))
+    ringm = Image.fromarray(contour_masks()["ring_vs_disc"])
+    img2 = Image.fromarray(np.random.default_rng(3).integers(0, 256, (96, 128, 3), dtype=np.uint8))
+    assert np.array_equal(np.asarray(shadow.add_shadow(img2, ringm)), np.asarray(osh.add_shadow(img2, ringm).convert("RGB")))
+    with pytest.raises(ValueError):
+        shadow.add_shadow(img2, hard)                     # Image.composite refuses mismatched sizes
 
 
 def test_add_shadow_to_mask_area_bit_exact_vs_pillow():
     import random
     img, hard, _ = synth(120, 90, seed=2)
-    boxes = shadow.mask_blobs(hard)
     for seed in (0, 1, 2):
-        bbox = random.Random(seed).choice(boxes)[:4]
-        ref = osh.add_shadow_to_mask_area_with_bbox(img, hard, bbox)
+        ref = osh.add_shadow_to_mask_area(img, hard, random.Random(seed))
         got = shadow.add_shadow_to_mask_area(img, hard, rng=random.Random(seed))
         assert np.array_equal(np.asarray(got), np.asarray(ref))
+    multi = Image.fromarray(contour_masks()["bridges"])
+    img2 = Image.fromarray(np.random.default_rng(4).integers(0, 256, (64, 80, 3), dtype=np.uint8))
+    for seed in range(6):                                  # random.choice walks OpenCV's list order
+        assert np.array_equal(np.asarray(shadow.add_shadow_to_mask_area(img2, multi, rng=random.Random(seed))),
+                              np.asarray(osh.add_shadow_to_mask_area(img2, multi, random.Random(seed))))
+
+
+@pytest.mark.parametrize("msize", [(60, 44), (150, 100), (90, 133)])
+@pytest.mark.parametrize("mode", ["L", "RGB"])
+def test_add_shadow_to_mask_area_mask_size_differs(msize, mode):
+    """shadow_for_attack.py:50-93 with mask.size != image.size (smaller, larger, other aspect): the layer is pasted at (0, 0)
+    on the mask's grid, the darkening goes through cv2's nearest resize -- per channel for an RGB mask whose channels differ."""
+    import random
+    rng = np.random.default_rng(8)
+    img = Image.fromarray(rng.integers(0, 256, (100, 120, 3), dtype=np.uint8))             # 120 x 100
+    w, h = msize
+    yy, xx = np.mgrid[0:h, 0:w]
+    m = ((((xx - w * 0.5) / (w * 0.32)) ** 2 + ((yy - h * 0.45) / (h * 0.3)) ** 2) <= 1).astype(np.uint8) * 255
+    m[1:4, 2:7] = 200
+    if mode == "RGB":
+        m = np.stack([m, m, m], 2)
+        m[5:9, 20:30, 1] = 0; m[h // 2, w // 2, 2] = 0                                      # channels that disagree
+        m[h - 4:h - 1, 3:9, 0] = 90
+    mask = Image.fromarray(m, mode)
+    for seed in (0, 3):
+        ref = osh.add_shadow_to_mask_area(img, mask, random.Random(seed))
+        got = shadow.add_shadow_to_mask_area(img, mask, rng=random.Random(seed))
+        assert got.size == img.size and np.array_equal(np.asarray(got), np.asarray(ref))
 
 
 @pytest.mark.parametrize("k", [5, 1, 3])

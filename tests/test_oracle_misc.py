@@ -73,3 +73,40 @@ def test_jpeg_roundtrip_oracle_is_pillow_exact():
             assert np.array_equal(oj.jpeg_roundtrip(a, q), _pil_jpeg_roundtrip(a, quality=q)), (name, q)
     with pytest.raises(ValueError):
         oj.jpeg_roundtrip(np.zeros((20, 32, 3), np.uint8))
+
+
+def test_contour_oracle_against_scipy_route():
+    """oracle/contours.py (Suzuki-Abe border following, Green's formula) against an independent route through scipy.ndimage
+    (fill the holes, label with 8-connectivity, area from the 2x2 cells of pixel centres) on random and hand-made masks:
+    same boxes, same doubled areas, same first pixels, same list order (last found first)."""
+    import numpy as np
+    from scipy import ndimage as ndi
+    from oracle import contours as oc
+
+    def scipy_route(m):
+        X = ndi.binary_fill_holes(m != 0)
+        lab, n = ndi.label(X, structure=np.ones((3, 3)))
+        Xp, L = np.pad(X, ((0, 1), (0, 1))), np.pad(lab, ((0, 1), (0, 1)))
+        k = Xp[:-1, :-1].astype(int) + Xp[:-1, 1:] + Xp[1:, :-1] + Xp[1:, 1:]
+        cl = np.maximum(np.maximum(L[:-1, :-1], L[:-1, 1:]), np.maximum(L[1:, :-1], L[1:, 1:]))
+        out = []
+        for c in range(1, n + 1):
+            ys, xs = np.nonzero(lab == c)
+            a2 = 2 * int(((k == 4) & (cl == c)).sum()) + int(((k == 3) & (cl == c)).sum())
+            out.append((xs.min(), ys.min(), xs.max() - xs.min() + 1, ys.max() - ys.min() + 1, a2, int((ys * m.shape[1] + xs).min())))
+        return [tuple(int(v) for v in e) for e in sorted(out, key=lambda e: -e[5])]
+
+    m = np.zeros((5, 5), np.uint8)
+    m[1, 1] = m[2, 1] = m[2, 2] = 1                                  # an L of three pixels: cv2.contourArea = 0.5
+    assert oc.external_contours(m) == [(1, 1, 2, 2, 1, 6)]
+    m = np.zeros((12, 14), np.uint8)
+    m[1:10, 1:12] = 1; m[3:8, 3:10] = 0; m[5, 5:7] = 1; m[0, 13] = 1   # ring, a blob nested in its hole, a speck on the frame
+    assert oc.external_contours(m) == [(1, 1, 11, 9, 160, 15), (13, 0, 1, 1, 0, 13)]
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        h, w = rng.integers(3, 24, 2)
+        m = (rng.random((h, w)) < rng.choice([0.3, 0.5, 0.65, 0.8])).astype(np.uint8) * 255
+        assert oc.external_contours(m) == scipy_route(m)
+    rgb = np.zeros((2, 2, 3), np.uint8)
+    rgb[0, 0] = (1, 0, 1); rgb[0, 1] = (0, 1, 0); rgb[1, 0] = (0, 0, 5); rgb[1, 1] = (0, 0, 4)
+    assert oc.cv_gray(rgb).tolist() == [[0, 1], [1, 0]]               # (R*4899 + G*9617 + B*1868 + 8192) >> 14
