@@ -424,20 +424,45 @@ class GaussianDiffusion:
                 - self._extract(self.sqrt_recipm1_alphas_cumprod, t, x_t.shape) * noise)
 
     def p_mean_variance(self, model, x_t, t, clip_denoised=True):
-        """diff_model.py:373-383 (the eps-predictor runs on the HIP kernels; the rest is the reference's torch chain)."""
-        x_recon = self.predict_start_from_noise(x_t, t, model(x_t, t))
-        if clip_denoised:
-            x_recon = torch.clamp(x_recon, min=-1., max=1.)
-        return self.q_posterior_mean_variance(x_recon, x_t, t)
+        """diff_model.py:373-383: (posterior mean, variance, clipped log-variance) of one step.  The mean comes from the same
+        fused kernel as the sampling loop (``advs_ddpm_posterior_step`` with zero noise); the two table look-ups are the
+        reference's ``_extract``."""
+        mean = self._posterior_step(model, x_t, t, clip_denoised, None)
+        return (mean, self._extract(self.posterior_variance, t, x_t.shape),
+                self._extract(self.posterior_log_variance_clipped, t, x_t.shape))
+
+    def _posterior_step(self, model, x_t, t, clip_denoised, noise):
+        """x_{t-1} = mean(x_t, eps) + [t != 0] * exp(0.5 * logvar) * noise on the device: eps-predictor forward, then the
+        fused update kernel per run of equal timesteps (the reference's loop passes one t for the whole batch)."""
+        lib = _lib.load()
+        dev = x_t.device
+        eps = model(x_t, t)
+        x = x_t.to(torch.float32).contiguous().clone()
+        z = torch.zeros_like(x) if noise is None else noise.to(dev, torch.float32).contiguous()
+        coef, tseq = self._posterior_tables(dev)
+        counter = torch.zeros((1,), dtype=torch.int32, device=dev)
+        t_out = torch.zeros((x.shape[0],), dtype=torch.int64, device=dev)
+        per = x[0].numel()
+        s = torch.cuda.current_stream(dev).cuda_stream
+        th = t.to("cpu", torch.int64).tolist()
+        i = 0
+        while i < len(th):
+            j = i
+            while j < len(th) and th[j] == th[i]:
+                j += 1
+            counter.fill_(self.timesteps - 1 - th[i])                    # the tables are in loop order t = T-1 .. 0
+            check(lib.advs_ddpm_posterior_step(x[i:j].data_ptr(), eps[i:j].data_ptr(), z[i:j].data_ptr(), ptr(coef), ptr(tseq),
+                                               self.timesteps, ptr(counter), ptr(t_out), j - i, per, 1 if clip_denoised else 0, s),
+                  "ddpm_posterior_step")
+            i = j
+        return x
 
     @torch.no_grad()
     def p_sample(self, model, x_t, t, clip_denoised=True, noise=None):
         """One ancestral step on caller tensors (diff_model.py:386-396); ``noise`` injects the randn_like."""
-        mean, _, logvar = self.p_mean_variance(model, x_t, t, clip_denoised=clip_denoised)
         if noise is None:
             noise = torch.randn_like(x_t)
-        mask = (t != 0).float().view(-1, *([1] * (len(x_t.shape) - 1)))
-        return mean + mask * (0.5 * logvar).exp() * noise
+        return self._posterior_step(model, x_t, t, clip_denoised, noise)
 
     def _posterior_tables(self, device):
         """[T][5] f32 per STEP in loop order (t = T-1 .. 0), rounded exactly where the reference rounds: f64 table ->

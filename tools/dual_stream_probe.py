@@ -1,0 +1,55 @@
+#!/usr/bin/env python
+"""Feasibility probe: does running the two halves of a batch as two forwards on two streams (GroupNorm of one half beside the
+convs of the other) beat one forward of the whole batch?  GPU box only.
+    python tools/dual_stream_probe.py [--batch 32] [--size 256]"""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from advshadow_amd import diff_model as dm  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--reps", type=int, default=10)
+    a = ap.parse_args()
+    torch.manual_seed(0)
+    net = dm.UNetModel(compute_dtype="bf16").to("cuda").eval()
+    dt = dm.dtype_code("bf16")
+    W = net.packed_weights(dt)
+    full = dm._ForwardEngine(net, W, a.batch, a.size, dt)
+    h1 = dm._ForwardEngine(net, W, a.batch // 2, a.size, dt)
+    h2 = dm._ForwardEngine(net, W, a.batch // 2, a.size, dt)
+    for e in (full, h1, h2):
+        e.x.normal_()
+        e.t.fill_(501)
+        e.run(); e.run()
+        e.stream.synchronize()
+
+    def timeit(fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / a.reps * 1e3
+
+    def both_serial():
+        h1.run(); h1.stream.synchronize(); h2.run(); h2.stream.synchronize()
+
+    def both_concurrent():
+        h1.run(); h2.run()
+
+    print(f"one forward, batch {a.batch}:                 {timeit(full.run):8.3f} ms")
+    print(f"two forwards of {a.batch // 2}, one after the other: {timeit(both_serial):8.3f} ms")
+    print(f"two forwards of {a.batch // 2}, two streams:         {timeit(both_concurrent):8.3f} ms")
+
+
+if __name__ == "__main__":
+    main()
