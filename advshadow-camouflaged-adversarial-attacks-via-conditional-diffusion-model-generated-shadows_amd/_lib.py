@@ -100,15 +100,21 @@ SIGNATURES = {
     "advs_graph_launch": [vp, vp],
     "advs_graph_destroy": [vp],
     "advs_event_create": [C.POINTER(vp)],
+    "advs_layernorm_bwd": [vp, vp, vp, vp, vp, C.c_longlong, i32, f32, i32, vp],
+    "advs_gelu": [vp, vp, C.c_longlong, i32, vp],
+    "advs_gelu_bwd": [vp, vp, vp, C.c_longlong, i32, vp],
+    "advs_attention_bwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "advs_scatter_row0": [vp, vp, i32, C.c_longlong, i32, i32, vp],
+    "advs_unpatchify_padded": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "advs_event_record": [vp, vp],
     "advs_event_elapsed_ms": [vp, vp, C.POINTER(f32)],
     "advs_event_destroy": [vp],
     "advs_stream_sync": [vp],
 }
 _RESTYPES = {"advs_last_error": C.c_char_p, "advs_groupnorm_scratch_bytes": sz, "advs_jpeg_scratch_bytes": sz,
-             "advs_mask_contours_work_bytes": sz}
+             "advs_mask_contours_work_bytes": sz, "advs_attention_bwd_scratch_bytes": sz}
 _EXTRA = {"advs_last_error": [], "advs_groupnorm_scratch_bytes": [i32, i32], "advs_jpeg_scratch_bytes": [i32, i32, i32],
-          "advs_mask_contours_work_bytes": [i32, i32, i32]}
+          "advs_mask_contours_work_bytes": [i32, i32, i32], "advs_attention_bwd_scratch_bytes": [i32, i32, i32]}
 
 _lib = None
 

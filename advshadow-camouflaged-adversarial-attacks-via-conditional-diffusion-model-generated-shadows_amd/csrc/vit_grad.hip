@@ -1,0 +1,279 @@
+// Backward-to-the-image pieces of the ViT victim (`loss.backward(); image.grad` of
+// tools/train_shadow.py:204-212 when the classifier is the HF ViT of ASR_fast.py:47-58, BASELINE config 4's victim).
+// Data gradients only (the attack never updates weights): every Linear's gradient is an advs_conv2d on the transposed
+// weight; what is here are the non-GEMM pieces -- LayerNorm, exact GELU, softmax attention, the patch embedding -- in the
+// order a reverse sweep of HF's ViTLayer needs them.  Token tensors are [B][n_pad][C] T with rows >= n_valid padding:
+// padding rows carry zero gradient in and out of every kernel.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------- LayerNorm backward
+// y = (x - mean) * rstd * gamma + beta per row.  dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma,
+// plus an optional second gradient stream `add` (the residual branch of the pre-norm block).  One wave per row, f32 math.
+template <typename T>
+__global__ void __launch_bounds__(256)
+layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma, const T* __restrict__ add,
+                     T* __restrict__ dx, long long rows, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long long row0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long stride = ((long long)gridDim.x * blockDim.x) >> 6;
+    for (long long row = row0; row < rows; row += stride) {
+        const T* xr = x + (size_t)row * C;
+        const T* gr = dy + (size_t)row * C;
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s += Elt<T>::ld(xr + c);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float mean = s / (float)C;
+        float q = 0.f;
+        for (int c = lane; c < C; c += 64) { const float d = Elt<T>::ld(xr + c) - mean; q = fmaf(d, d, q); }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        const float rstd = 1.0f / sqrtf(q / (float)C + eps);
+        float m1 = 0.f, m2 = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            const float g = Elt<T>::ld(gr + c) * gamma[c];
+            const float xh = (Elt<T>::ld(xr + c) - mean) * rstd;
+            m1 += g; m2 = fmaf(g, xh, m2);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { m1 += __shfl_xor(m1, o); m2 += __shfl_xor(m2, o); }
+        m1 /= (float)C; m2 /= (float)C;
+        for (int c = lane; c < C; c += 64) {
+            const float g = Elt<T>::ld(gr + c) * gamma[c];
+            const float xh = (Elt<T>::ld(xr + c) - mean) * rstd;
+            float v = rstd * (g - m1 - xh * m2);
+            if (add) v += Elt<T>::ld(add + (size_t)row * C + c);
+            Elt<T>::st(dx + (size_t)row * C + c, v);
+        }
+    }
+}
+extern "C" int advs_layernorm_bwd(const void* dy, const void* x, const float* gamma, const void* add, void* dx, long long rows,
+                                  int c, float eps, int dtype, void* stream) {
+    ADVS_REQUIRE(dtype_ok(dtype), "advs_layernorm_bwd: unknown dtype code %d", dtype);
+    ADVS_REQUIRE(dy && x && gamma && dx && rows > 0 && c > 0, "layernorm_bwd: bad args");
+    const long long blocks = (rows + 3) / 4;
+    const int grid = (int)(blocks < 8192 ? blocks : 8192);
+    ADVS_SWITCH_T(dtype, layernorm_bwd_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T*)dy, (const T*)x, gamma, (const T*)add,
+                                                                                       (T*)dx, rows, c, eps));
+    ADVS_CHECK_LAUNCH("layernorm_bwd");
+    return ADVS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- exact GELU, both ways
+// forward: y = 0.5 x (1 + erf(x / sqrt 2)) (the activation of HF's ViTIntermediate, kept apart from the GEMM in the gradient plan so
+// that the pre-activation survives); backward: dx = dy * (Phi(x) + x phi(x)).
+template <typename T>
+__global__ void gelu_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ out, size_t n, int backward) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = Elt<T>::ld(x + i);
+        const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+        float r;
+        if (backward) r = Elt<T>::ld(dy + i) * (cdf + v * 0.39894228040143267794f * expf(-0.5f * v * v));
+        else r = v * cdf;
+        Elt<T>::st(out + i, r);
+    }
+}
+extern "C" int advs_gelu(const void* x, void* y, long long n, int dtype, void* stream) {
+    ADVS_REQUIRE(dtype_ok(dtype) && x && y && n > 0, "advs_gelu: bad args");
+    const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    ADVS_SWITCH_T(dtype, gelu_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T*)x, nullptr, (T*)y, (size_t)n, 0));
+    ADVS_CHECK_LAUNCH("gelu");
+    return ADVS_OK;
+}
+extern "C" int advs_gelu_bwd(const void* x, const void* dy, void* dx, long long n, int dtype, void* stream) {
+    ADVS_REQUIRE(dtype_ok(dtype) && x && dy && dx && n > 0, "advs_gelu_bwd: bad args");
+    const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    ADVS_SWITCH_T(dtype, gelu_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T*)x, (const T*)dy, (T*)dx, (size_t)n, 1));
+    ADVS_CHECK_LAUNCH("gelu_bwd");
+    return ADVS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- attention backward
+// softmax(q k^T / sqrt d) v per (image, head), tokens padded to n rows of which the first n_valid are real keys (as
+// advs_attention_masked).  Given dO: D_i = dO_i . O_i;  P recomputed from q, k;  dP_ij = dO_i . v_j;  dS = P o (dP - D);
+//   dq_i = s sum_j dS_ij k_j,   dk_j = s sum_i dS_ij q_i,   dv_j = sum_i P_ij dO_i      (s = 1 / sqrt d).
+// Two passes, f32 VALU arithmetic (the sequences are a few hundred tokens: 197 for ViT-B/16; the layer's GEMMs dominate):
+//   pass 1, a thread per query row: online row max / sum over the keys, then a second sweep that recomputes the scores, forms
+//           P and dS, accumulates dq and writes P / dS TRANSPOSED to scratch [B][heads][key j][query i] (lanes = queries: coalesced);
+//   pass 2, a thread per key row: dk, dv from its scratch row.
+// K / V (pass 1) and Q / dO (pass 2) of the head sit in LDS as f32 and are read as broadcasts.  D = head width rounded up
+// (compile time, so q / dO / the accumulators stay in registers).
+template <typename T, int D>
+__global__ void __launch_bounds__(256)
+attn_bwd_q_kernel(const T* __restrict__ qkv, const T* __restrict__ o, const T* __restrict__ dO, T* __restrict__ dqkv,
+                  float* __restrict__ sP, float* __restrict__ sdS, int n, int n_valid, int heads, int d, int ld, int q_off, int k_off,
+                  int v_off, int head_stride, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];       // K [n_valid][D], V [n_valid][D], zero beyond d
+    float* sK = lds;
+    float* sV = lds + (size_t)n_valid * D;
+    const int b = blockIdx.z, hd = blockIdx.y, tid = threadIdx.x;
+    const T* base = qkv + (size_t)b * n * ld;
+    for (int i = tid; i < n_valid * D; i += blockDim.x) {
+        const int j = i / D, c = i - j * D;
+        sK[i] = c < d ? Elt<T>::ld(base + (size_t)j * ld + k_off + hd * head_stride + c) : 0.f;
+        sV[i] = c < d ? Elt<T>::ld(base + (size_t)j * ld + v_off + hd * head_stride + c) : 0.f;
+    }
+    __syncthreads();
+    const int C = heads * d;
+    for (int i = blockIdx.x * blockDim.x + tid; i < n; i += gridDim.x * blockDim.x) {
+        float* pc = sP + ((size_t)b * heads + hd) * n * n + i;         // element (j, i) at pc[j * n]
+        float* dc = sdS + ((size_t)b * heads + hd) * n * n + i;
+        T* dq = dqkv + ((size_t)b * n + i) * ld + q_off + hd * head_stride;
+        if (i >= n_valid) {                                            // padding query: no gradient flows through it
+            for (int j = 0; j < n; ++j) { pc[(size_t)j * n] = 0.f; dc[(size_t)j * n] = 0.f; }
+            for (int c = 0; c < d; ++c) Elt<T>::st(dq + c, 0.f);
+            continue;
+        }
+        float q[D], g[D], acc[D];
+        const T* qp = base + (size_t)i * ld + q_off + hd * head_stride;
+        const T* gp = dO + ((size_t)b * n + i) * C + hd * d;
+        const T* op = o + ((size_t)b * n + i) * C + hd * d;
+        float Dn = 0.f;
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            q[c] = c < d ? Elt<T>::ld(qp + c) * scale : 0.f;           // the scale rides on q
+            g[c] = c < d ? Elt<T>::ld(gp + c) : 0.f;
+            if (c < d) Dn = fmaf(g[c], Elt<T>::ld(op + c), Dn);
+            acc[c] = 0.f;
+        }
+        float mx = -INFINITY, l = 0.f;
+        for (int j = 0; j < n_valid; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < D; ++c) s = fmaf(q[c], sK[j * D + c], s);
+            const float m2 = fmaxf(mx, s);
+            l = l * expf(mx - m2) + expf(s - m2);
+            mx = m2;
+        }
+        const float inv = 1.0f / l;
+        for (int j = 0; j < n_valid; ++j) {
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int c = 0; c < D; ++c) { s = fmaf(q[c], sK[j * D + c], s); dp = fmaf(g[c], sV[j * D + c], dp); }
+            const float p = expf(s - mx) * inv;
+            const float ds = p * (dp - Dn);
+            pc[(size_t)j * n] = p; dc[(size_t)j * n] = ds;
+#pragma unroll
+            for (int c = 0; c < D; ++c) acc[c] = fmaf(ds, sK[j * D + c], acc[c]);
+        }
+        for (int j = n_valid; j < n; ++j) { pc[(size_t)j * n] = 0.f; dc[(size_t)j * n] = 0.f; }
+#pragma unroll
+        for (int c = 0; c < D; ++c)
+            if (c < d) Elt<T>::st(dq + c, acc[c] * scale);
+    }
+}
+template <typename T, int D>
+__global__ void __launch_bounds__(256)
+attn_bwd_kv_kernel(const T* __restrict__ qkv, const T* __restrict__ dO, T* __restrict__ dqkv, const float* __restrict__ sP,
+                   const float* __restrict__ sdS, int n, int n_valid, int heads, int d, int ld, int q_off, int k_off, int v_off,
+                   int head_stride, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];       // Q [n_valid][D], dO [n_valid][D]
+    float* sQ = lds;
+    float* sG = lds + (size_t)n_valid * D;
+    const int b = blockIdx.z, hd = blockIdx.y, tid = threadIdx.x, C = heads * d;
+    const T* base = qkv + (size_t)b * n * ld;
+    for (int i = tid; i < n_valid * D; i += blockDim.x) {
+        const int r = i / D, c = i - r * D;
+        sQ[i] = c < d ? Elt<T>::ld(base + (size_t)r * ld + q_off + hd * head_stride + c) : 0.f;
+        sG[i] = c < d ? Elt<T>::ld(dO + ((size_t)b * n + r) * C + hd * d + c) : 0.f;
+    }
+    __syncthreads();
+    for (int j = blockIdx.x * blockDim.x + tid; j < n; j += gridDim.x * blockDim.x) {
+        T* dk = dqkv + ((size_t)b * n + j) * ld + k_off + hd * head_stride;
+        T* dv = dqkv + ((size_t)b * n + j) * ld + v_off + hd * head_stride;
+        float ak[D], av[D];
+#pragma unroll
+        for (int c = 0; c < D; ++c) { ak[c] = 0.f; av[c] = 0.f; }
+        if (j < n_valid) {
+            const float* pr = sP + (((size_t)b * heads + hd) * n + j) * n;          // row j: all queries
+            const float* dr = sdS + (((size_t)b * heads + hd) * n + j) * n;
+            for (int i = 0; i < n_valid; ++i) {
+                const float p = pr[i], ds = dr[i];
+#pragma unroll
+                for (int c = 0; c < D; ++c) { ak[c] = fmaf(ds, sQ[i * D + c], ak[c]); av[c] = fmaf(p, sG[i * D + c], av[c]); }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < D; ++c)
+            if (c < d) { Elt<T>::st(dk + c, ak[c] * scale); Elt<T>::st(dv + c, av[c]); }
+    }
+}
+extern "C" size_t advs_attention_bwd_scratch_bytes(int b, int n, int heads) { return (size_t)b * heads * n * n * 2 * sizeof(float); }
+
+template <typename T, int D>
+static int attn_bwd_launch(const void* qkv, const void* out, const void* d_out, void* d_qkv, float* sP, float* sdS, int b, int n,
+                           int n_valid, int heads, int d, int ld, int q_off, int k_off, int v_off, int head_stride, hipStream_t st) {
+    const size_t lds = (size_t)2 * n_valid * D * sizeof(float);
+    ADVS_REQUIRE(lds <= 160 * 1024, "attention_bwd: %d keys x d %d do not fit the LDS (this path is for short sequences)", n_valid, d);
+    static bool attr_set = false;
+    if (!attr_set) {
+        ADVS_HIP(hipFuncSetAttribute((const void*)attn_bwd_q_kernel<T, D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ADVS_HIP(hipFuncSetAttribute((const void*)attn_bwd_kv_kernel<T, D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const float scale = (float)(1.0 / sqrt((double)d));
+    const dim3 grid(cdiv(n, 256), heads, b);
+    attn_bwd_q_kernel<T, D><<<grid, 256, lds, st>>>((const T*)qkv, (const T*)out, (const T*)d_out, (T*)d_qkv, sP, sdS, n, n_valid, heads, d,
+                                                    ld, q_off, k_off, v_off, head_stride, scale);
+    ADVS_CHECK_LAUNCH("attention_bwd (queries)");
+    attn_bwd_kv_kernel<T, D><<<grid, 256, lds, st>>>((const T*)qkv, (const T*)d_out, (T*)d_qkv, sP, sdS, n, n_valid, heads, d, ld, q_off,
+                                                     k_off, v_off, head_stride, scale);
+    ADVS_CHECK_LAUNCH("attention_bwd (keys)");
+    return ADVS_OK;
+}
+extern "C" int advs_attention_bwd(const void* qkv, const void* out, const void* d_out, void* d_qkv, void* scratch, int b, int n,
+                                  int n_valid, int heads, int d, int ld, int q_off, int k_off, int v_off, int head_stride, int dtype,
+                                  void* stream) {
+    ADVS_REQUIRE(dtype_ok(dtype), "advs_attention_bwd: unknown dtype code %d", dtype);
+    ADVS_REQUIRE(qkv && out && d_out && d_qkv && scratch && b > 0 && n > 0 && n_valid > 0 && n_valid <= n && heads > 0, "attention_bwd: bad args");
+    ADVS_REQUIRE(d > 0 && d <= 64, "attention_bwd: d=%d must be in 1..64", d);
+    float* sP = (float*)scratch;
+    float* sdS = sP + (size_t)b * heads * n * n;
+    if (d <= 32) ADVS_SWITCH_T(dtype, return (attn_bwd_launch<T, 32>(qkv, out, d_out, d_qkv, sP, sdS, b, n, n_valid, heads, d, ld, q_off, k_off, v_off, head_stride, (hipStream_t)stream)));
+    ADVS_SWITCH_T(dtype, return (attn_bwd_launch<T, 64>(qkv, out, d_out, d_qkv, sP, sdS, b, n, n_valid, heads, d, ld, q_off, k_off, v_off, head_stride, (hipStream_t)stream)));
+    return ADVS_ERR_ARG;                    // not reached
+}
+
+// ---------------------------------------------------------------------------------------------- head and embedding
+// dtok[b][0][:] = d_cls[b][:] (f32 -> T); the other rows of dtok are left as they are (zero: the head reads the CLS row only)
+template <typename T>
+__global__ void scatter_row0_kernel(const float* __restrict__ src, T* __restrict__ dst, int B, long long row_stride, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, c = i - b * C;
+    Elt<T>::st(dst + (size_t)b * row_stride * C + c, src[i]);
+}
+extern "C" int advs_scatter_row0(const float* src, void* dst, int b, long long row_stride, int c, int dtype, void* stream) {
+    ADVS_REQUIRE(dtype_ok(dtype) && src && dst && b > 0 && c > 0 && row_stride > 0, "advs_scatter_row0: bad args");
+    ADVS_SWITCH_T(dtype, scatter_row0_kernel<T><<<cdiv((long long)b * c, 256), 256, 0, (hipStream_t)stream>>>(src, (T*)dst, b, row_stride, c));
+    ADVS_CHECK_LAUNCH("scatter_row0");
+    return ADVS_OK;
+}
+// inverse of advs_patchify_padded for gradients: dx[b][c][py*ps+ky][px*ps+kx] = dcols[b][row_off + py*gw + px][(c*ps+ky)*ps+kx],
+// dcols rows `rows_per_image` apart per image and kpad long (the token-gradient layout: row_off = 1 skips the CLS row).
+template <typename T>
+__global__ void unpatchify_kernel(const T* __restrict__ dcols, float* __restrict__ dx, int B, int Cin, int H, int W, int ps, int Kp,
+                                  int rows_per_image, int row_off) {
+    const int gw = W / ps;
+    const size_t total = (size_t)B * Cin * H * W;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W);
+        size_t r = i / W;
+        const int y = (int)(r % H); r /= H;
+        const int c = (int)(r % Cin);
+        const int b = (int)(r / Cin);
+        const int py = y / ps, ky = y - py * ps, px = x / ps, kx = x - px * ps;
+        dx[i] = Elt<T>::ld(dcols + ((size_t)b * rows_per_image + row_off + py * gw + px) * Kp + (c * ps + ky) * ps + kx);
+    }
+}
+extern "C" int advs_unpatchify_padded(const void* dcols, float* dx_nchw, int b, int cin, int h, int w, int patch, int kpad,
+                                      int rows_per_image, int row_off, int dtype, void* stream) {
+    ADVS_REQUIRE(dtype_ok(dtype) && dcols && dx_nchw && b > 0 && cin > 0 && patch > 0 && h % patch == 0 && w % patch == 0, "unpatchify: bad args");
+    ADVS_REQUIRE(kpad >= cin * patch * patch && row_off >= 0 && rows_per_image >= row_off + (h / patch) * (w / patch), "unpatchify: bad row layout");
+    const size_t total = (size_t)b * cin * h * w;
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    ADVS_SWITCH_T(dtype, unpatchify_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T*)dcols, dx_nchw, b, cin, h, w, patch, kpad,
+                                                                                   rows_per_image, row_off));
+    ADVS_CHECK_LAUNCH("unpatchify");
+    return ADVS_OK;
+}

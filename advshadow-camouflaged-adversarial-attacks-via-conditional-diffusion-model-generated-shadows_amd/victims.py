@@ -344,7 +344,7 @@ def _patch_proj(w, dt):
     return pack_conv_weight(w2.reshape(w2.shape[0], kpad, 1, 1), dt)
 
 
-class ViTVictim(nn.Module):
+class ViTVictim(_InputGradient, nn.Module):
     """ViT-B/16-style classifier with HF's parameter names (``AutoModelForImageClassification`` of
     ASR_fast.py:47-51; config C4 of BASELINE.json), forward on the HIP kernels: patch projection and every
     Linear as implicit-GEMM 1x1 convs (bias / GELU / residual in the epilogue), LayerNorm, flash attention
@@ -439,6 +439,150 @@ class ViTVictim(nn.Module):
         cur.wait_stream(eng.stream)
         out.record_stream(cur)
         return _Logits(out)
+
+    # ---- backward to the image (the gradient attack of tools/train_shadow.py:177-221 with this victim) ------------------
+    def packed_grad_weights(self, dt):
+        """Every Linear's weight transposed (its data gradient is a GEMM against W: rows of d_y times W[out][in])."""
+        ver = self._version()
+        hit = self._packed.get(("grad", dt))
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        self.packed_weights(dt)
+        sd = {k: v.detach() for k, v in self.state_dict().items()}
+        C = self.cfg["hidden"]
+        linT = lambda w: pack_conv_weight(w.float().t().contiguous().reshape(w.shape[1], w.shape[0], 1, 1), dt)
+        G = {}
+        for i in range(self.cfg["layers"]):
+            p = f"vit.encoder.layer.{i}"
+            a = p + ".attention.attention."
+            wqkv = torch.cat([sd[a + n + ".weight"].float() for n in ("query", "key", "value")], 0)      # [3C, C]
+            G[p + ".qkvT"] = linT(wqkv)
+            for src, dst in ((".attention.output.dense", ".oT"), (".intermediate.dense", ".fc1T"), (".output.dense", ".fc2T")):
+                G[p + dst] = linT(sd[p + src + ".weight"])
+        wp = sd["vit.embeddings.patch_embeddings.projection.weight"].float().reshape(C, -1)           # [C, 3*ps*ps]
+        k = wp.shape[1]
+        kpad = -(-k // 64) * 64
+        wt = torch.zeros((kpad, C), dtype=torch.float32, device=wp.device)
+        wt[:k] = wp.t()
+        G["projT"] = pack_conv_weight(wt.reshape(kpad, C, 1, 1), dt)
+        G["cls.wT"] = sd["classifier.weight"].float().t().contiguous()
+        self._packed[("grad", dt)] = (ver, G)
+        return G
+
+    def grad_engine(self, batch, size=None, dtype=None):
+        """Static plan of forward + backward-to-the-image (d cross_entropy / d pixel_values) for [batch,3,S,S] inputs."""
+        if size is not None and size != self.cfg["image"]:
+            raise ValueError(f"ViTVictim was built for {self.cfg['image']}x{self.cfg['image']} inputs, not {size}")
+        if self.cfg.get("head") == "cls_mean" or self.cfg.get("layerscale"):
+            raise _lib.AdvsError("no HIP backward plan for this ViT variant (DINOv2 head / LayerScale)")
+        dt = dtype_code(dtype if dtype is not None else self.compute_dtype)
+        W, G = self.packed_weights(dt), self.packed_grad_weights(dt)
+        eng = self._engines.get(("grad", batch, dt))
+        if eng is None:
+            eng = _ViTGradEngine(self, W, G, batch, dt)
+            self._engines[("grad", batch, dt)] = eng
+        return eng
+
+
+class _ViTGradEngine:
+    """ViT forward with what the reverse sweep needs retained (the residual stream before each LayerNorm, qkv, the attention output,
+    the MLP pre-activation), then HF's ViTLayer backwards (pre-norm blocks):
+        d f = dT' W_fc2;  d pre = d f * gelu'(pre);  d h = dT' + LN2'(d pre W_fc1; h)
+        d att = d h W_o;  d qkv = attention'(d att; qkv, att);  dT = d h + LN1'(d qkv W_qkv; T)
+    down to the patch columns (d emb W_proj) and the image (advs_unpatchify_padded).  Only the CLS row of the last LayerNorm
+    receives gradient from the head; padding rows carry zeros throughout."""
+
+    def __init__(self, model, W, G, batch, dt):
+        cfg = model.cfg
+        dev = next(model.parameters()).device
+        self.model, self.stream = model, torch.cuda.Stream(device=dev)
+        C, heads, S, ps, eps = cfg["hidden"], cfg["heads"], cfg["image"], cfg["patch"], cfg["eps"]
+        g = S // ps
+        npatch, n_tok = g * g, g * g + 1
+        n_pad = (n_tok + 63) // 64 * 64
+        d = C // heads
+        rows = batch * n_pad
+        with torch.cuda.device(dev):
+            bld = Builder(dev, dt, self.stream, batch)
+            lib, plan = bld.lib, bld.plan
+            self.x = torch.zeros((batch, 3, S, S), dtype=torch.float32, device=dev)
+            self.labels = torch.zeros((batch,), dtype=torch.int64, device=dev)
+            self.grad = torch.zeros((batch, 3, S, S), dtype=torch.float32, device=dev)
+            kpad = -(-3 * ps * ps // 64) * 64
+            # ---- forward (as _ViTEngine, GELU as its own pass, activations retained)
+            patches = bld.buf((batch, g, g, kpad))
+            plan.add(lib.advs_patchify_padded, ptr(self.x), ptr(patches), batch, 3, S, S, ps, kpad, dt, keep=(self.x, patches))
+            emb = bld.conv(patches, W["proj.w"], C, bias=W["proj.b"], ksize=1, pad=0)
+            bld.free(patches)
+            tok = bld.buf((batch, 1, n_pad, C))
+            plan.add(lib.advs_vit_assemble, ptr(emb), ptr(W["cls"]), ptr(W["pos"]), ptr(tok), batch, npatch, n_pad, C, dt, keep=(emb, tok))
+            bld.free(emb)
+            saved = []
+            for i in range(cfg["layers"]):
+                p = f"vit.encoder.layer.{i}"
+                ln = bld.layernorm(tok, W[p + ".layernorm_before.g"], W[p + ".layernorm_before.b"], eps)
+                qkv = bld.conv(ln, W[p + ".qkv.w"], 3 * C, bias=W[p + ".qkv.b"], ksize=1, pad=0)
+                bld.free(ln)
+                att = bld.attention(qkv, heads, d, 0, C, 2 * C, d, n_valid=n_tok)
+                h = bld.conv(att, W[p + ".o.w"], C, bias=W[p + ".o.b"], residual=tok, ksize=1, pad=0)
+                ln = bld.layernorm(h, W[p + ".layernorm_after.g"], W[p + ".layernorm_after.b"], eps)
+                pre = bld.conv(ln, W[p + ".fc1.w"], cfg["mlp"], bias=W[p + ".fc1.b"], ksize=1, pad=0)
+                bld.free(ln)
+                f = bld.buf(tuple(pre.shape))
+                plan.add(lib.advs_gelu, ptr(pre), ptr(f), pre.numel(), dt, keep=(pre, f))
+                nxt = bld.conv(f, W[p + ".fc2.w"], C, bias=W[p + ".fc2.b"], residual=h, ksize=1, pad=0)
+                bld.free(f)
+                saved.append((p, tok, qkv, att, h, pre))
+                tok = nxt
+            ln = bld.layernorm(tok, W["ln.g"], W["ln.b"], eps)
+            cls = bld.buf((batch, C), torch.float32)
+            plan.add(lib.advs_gather_rows_f32, ptr(ln), ptr(cls), batch, n_pad, C, dt, keep=(ln, cls))
+            bld.free(ln)
+            self.logits = bld.linear(cls, W["cls.w"], W["cls.b"])
+            # ---- backward
+            K = self.logits.shape[1]
+            gl = bld.buf((batch, K), torch.float32)
+            plan.add(lib.advs_softmax_ce_grad, ptr(self.logits), ptr(self.labels), ptr(gl), batch, K, 1.0, keep=(self.logits, self.labels, gl))
+            gcls = bld.linear(gl, G["cls.wT"], None)                       # [B, C] f32
+            dln = torch.zeros((batch, 1, n_pad, C), dtype=bld.tdt, device=dev)    # rows other than the CLS row stay zero for good
+            plan.add(lib.advs_scatter_row0, ptr(gcls), ptr(dln), batch, n_pad, C, dt, keep=(gcls, dln))
+            scratch = torch.empty(lib.advs_attention_bwd_scratch_bytes(batch, n_pad, heads), dtype=torch.uint8, device=dev)
+
+            def ln_bwd(dy, x, gamma, add):
+                dx = bld.buf(tuple(x.shape))
+                plan.add(lib.advs_layernorm_bwd, ptr(dy), ptr(x), ptr(gamma), ptr(add), ptr(dx), rows, C, float(eps), dt,
+                         keep=(dy, x, gamma, add, dx))
+                return dx
+
+            dT = ln_bwd(dln, tok, W["ln.g"], None)
+            bld.free(tok)
+            for p, t_in, qkv, att, h, pre in reversed(saved):
+                df = bld.conv(dT, G[p + ".fc2T"], cfg["mlp"], ksize=1, pad=0)
+                dpre = bld.buf(tuple(pre.shape))
+                plan.add(lib.advs_gelu_bwd, ptr(pre), ptr(df), ptr(dpre), pre.numel(), dt, keep=(pre, df, dpre))
+                bld.free(df); bld.free(pre)
+                dl2 = bld.conv(dpre, G[p + ".fc1T"], C, ksize=1, pad=0)
+                bld.free(dpre)
+                dh = ln_bwd(dl2, h, W[p + ".layernorm_after.g"], dT)
+                bld.free(dl2); bld.free(dT); bld.free(h)
+                datt = bld.conv(dh, G[p + ".oT"], C, ksize=1, pad=0)
+                dqkv = bld.buf(tuple(qkv.shape))
+                plan.add(lib.advs_attention_bwd, ptr(qkv), ptr(att), ptr(datt), ptr(dqkv), ptr(scratch), batch, n_pad, n_tok, heads, d,
+                         3 * C, 0, C, 2 * C, d, dt, keep=(qkv, att, datt, dqkv, scratch))
+                bld.free(datt); bld.free(qkv); bld.free(att)
+                dl1 = bld.conv(dqkv, G[p + ".qkvT"], C, ksize=1, pad=0)
+                bld.free(dqkv)
+                dT = ln_bwd(dl1, t_in, W[p + ".layernorm_before.g"], dh)
+                bld.free(dl1); bld.free(dh); bld.free(t_in)
+            # token gradients -> patch columns (every row; the CLS and padding rows are never read) -> image
+            dcols = bld.conv(dT, G["projT"], kpad, ksize=1, pad=0)
+            bld.free(dT)
+            plan.add(lib.advs_unpatchify_padded, ptr(dcols), ptr(self.grad), batch, 3, S, S, ps, kpad, n_pad, 1, dt, keep=(dcols, self.grad))
+            self.plan, self.captured = plan, False
+            torch.cuda.synchronize(dev)
+
+    def run(self):
+        _ViTEngine.run(self)
 
 
 class _ViTEngine:

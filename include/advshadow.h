@@ -227,6 +227,29 @@ int advs_to_uint8(const float* x, uint8_t* y, size_t n, int clamp, void* stream)
 /* [0,1] float image -> uint8 by clamp(x*255) truncated (ToPILImage's pic.mul(255).byte()).          */
 int advs_unit_to_uint8(const float* x, uint8_t* y, size_t n, void* stream);
 
+/* ---- ViT victim backwards (SURVEY 8f rank 4 for the HF ViT of ASR_fast.py:47-58; csrc/vit_grad.hip) ------------------------
+ * The data-gradient pieces `loss.backward(); image.grad` (tools/train_shadow.py:204-212) needs beyond the Linear layers (whose
+ * gradients are advs_conv2d on transposed weights).  Token tensors [rows][c] in the compute dtype; f32 arithmetic inside.
+ * layernorm_bwd: dx = d LayerNorm(x; gamma, eps) applied to dy, + `add` (the residual stream's gradient, may be null).          */
+int advs_layernorm_bwd(const void* dy, const void* x, const float* gamma, const void* add, void* dx, long long rows,
+                       int c, float eps, int dtype, void* stream);
+/* exact (erf) GELU as its own pass, and its gradient dx = dy * (Phi(x) + x phi(x)) from the PRE-activation x.                    */
+int advs_gelu(const void* x, void* y, long long n, int dtype, void* stream);
+int advs_gelu_bwd(const void* x, const void* dy, void* dx, long long n, int dtype, void* stream);
+/* Gradient of advs_attention_masked: qkv / d_qkv laid out as there, out = the forward's output, d_out its gradient ([b][n][heads*d]);
+ * d <= 64, keys and head width small enough for 2 * n_valid * d f32 in LDS (ViT-B/16: 197 x 64).  scratch:
+ * advs_attention_bwd_scratch_bytes(b, n, heads) bytes ([2][b][heads][n][n] f32: P and dS, transposed).                            */
+size_t advs_attention_bwd_scratch_bytes(int b, int n, int heads);
+int advs_attention_bwd(const void* qkv, const void* out, const void* d_out, void* d_qkv, void* scratch, int b, int n,
+                       int n_valid, int heads, int d, int ld, int q_off, int k_off, int v_off, int head_stride, int dtype,
+                       void* stream);
+/* dst[b * row_stride][0..c) = src[b][0..c) (f32 -> compute dtype): the classifier head's gradient enters the CLS row.          */
+int advs_scatter_row0(const float* src, void* dst, int b, long long row_stride, int c, int dtype, void* stream);
+/* Inverse of advs_patchify_padded for gradients: image gradient (NCHW f32) from the patch-column gradients, which sit in rows
+ * row_off + patch index of a [b][rows_per_image][kpad] matrix (the token layout: row_off = 1 skips the CLS row).               */
+int advs_unpatchify_padded(const void* dcols, float* dx_nchw, int b, int cin, int h, int w, int patch, int kpad,
+                           int rows_per_image, int row_off, int dtype, void* stream);
+
 /* ---- shadow composite, image hand-off, metrics ------------------------------------------------
  * Closed form of apply_shadow (tools/train_shadow.py:242-256,262-266; ddim2/test.py:830-871; with
  * ntaps = 1, taps = {1}: ddim2/diff_model2.py:615-654): circular mask at centers[b] = (cx, cy) with

@@ -340,3 +340,107 @@ def test_vgg16_input_gradient_and_attack_match_autograd():
     got = adversarial.apply_adversarial_perturbation(net, x[0], labels, dev(), m, 1 / 64, 1 / 256, 2).cpu()
     assert ((got - ref_adv).abs() < 1e-6).float().mean().item() > 0.97
     assert (got - ref_adv).abs().max().item() <= 2 * (1 / 64) + 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ ViT victim backwards
+def test_vit_backward_pieces_match_autograd():
+    """LayerNorm, exact GELU and masked softmax attention gradients (csrc/vit_grad.hip) against torch autograd, fp32."""
+    import math
+    lib = OneOp("fp32", 1).b.lib
+    s = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(3)
+    # LayerNorm (+ a second gradient stream)
+    x = torch.randn(10, 96, generator=g).requires_grad_(True)
+    gam, bet = torch.rand(96, generator=g) + 0.5, torch.randn(96, generator=g)
+    dy, add = torch.randn(10, 96, generator=g), torch.randn(10, 96, generator=g)
+    F.layer_norm(x, (96,), gam, bet, 1e-12).backward(dy)
+    dx = torch.empty(10, 96, device=dev())
+    args = [t.to(dev()).contiguous() for t in (dy, x.detach(), gam, add)]
+    assert lib.advs_layernorm_bwd(ptr(args[0]), ptr(args[1]), ptr(args[2]), ptr(args[3]), ptr(dx), 10, 96, 1e-12, 0, s) == 0
+    assert (dx.cpu() - (x.grad + add)).abs().max().item() < 2e-5
+    # GELU both ways
+    x = (torch.randn(1000, generator=g) * 2).requires_grad_(True)
+    dy = torch.randn(1000, generator=g)
+    y = F.gelu(x)
+    y.backward(dy)
+    xd, dyd = x.detach().to(dev()), dy.to(dev())
+    yd, dxd = torch.empty_like(xd), torch.empty_like(xd)
+    assert lib.advs_gelu(ptr(xd), ptr(yd), 1000, 0, s) == 0 and lib.advs_gelu_bwd(ptr(xd), ptr(dyd), ptr(dxd), 1000, 0, s) == 0
+    assert (yd.cpu() - y.detach()).abs().max().item() < 1e-6 and (dxd.cpu() - x.grad).abs().max().item() < 2e-6
+    # attention: 2 images, 3 heads of 24, 50 valid tokens in 64 rows; q | k | v blocks of width heads * d
+    B, H, d, n, nv = 2, 3, 24, 64, 50
+    C = H * d
+    qkv = torch.randn(B, n, 3 * C, generator=g).requires_grad_(True)
+    q, k, v = (qkv[:, :, i * C:(i + 1) * C].reshape(B, n, H, d).transpose(1, 2) for i in range(3))
+    sc = (q @ k.transpose(-1, -2)) / math.sqrt(d)
+    sc = sc.masked_fill(torch.arange(n)[None, None, None, :] >= nv, float("-inf"))
+    o = (torch.softmax(sc, -1) @ v).transpose(1, 2).reshape(B, n, C)
+    do = torch.randn(B, n, C, generator=g)
+    do[:, nv:] = 0                                         # padding rows carry no gradient
+    o.backward(do)
+    qd, od, dod = qkv.detach().to(dev()), o.detach().to(dev()).contiguous(), do.to(dev())
+    dq = torch.full_like(qd, 7.0)
+    scratch = torch.empty(lib.advs_attention_bwd_scratch_bytes(B, n, H), dtype=torch.uint8, device=dev())
+    assert lib.advs_attention_bwd(ptr(qd), ptr(od), ptr(dod), ptr(dq), ptr(scratch), B, n, nv, H, d, 3 * C, 0, C, 2 * C, d, 0, s) == 0
+    torch.cuda.synchronize()
+    ref = qkv.grad.clone()
+    ref[:, nv:] = 0
+    assert (dq.cpu() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("cfg,batch", [(dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=4, intermediate_size=256, patch_size=8,
+                                             image_size=64), 3), ({}, 2)])
+def test_vit_input_gradient_matches_transformers_autograd(cfg, batch):
+    """d cross_entropy / d pixel_values of the HF ViT (BASELINE config 4's victim) from the HIP backward plan against autograd over
+    the installed transformers implementation itself (so this row is pinned, unlike the ResNet / VGG restatements): a small
+    config (65 tokens in 128 rows, d = 32) and ViT-B/16 (197 tokens in 256 rows, 12 layers); fp32, within 1e-3 of the largest
+    component; logits within 2e-4; replays bit-identical; the gradient of an image does not depend on its batch."""
+    from advshadow_amd.victims import ViTVictim
+    from oracle import victims as ov
+    hf = ov.hf_vit(37 if not cfg else 5, seed=2 if not cfg else 3, **cfg)
+    net = ViTVictim(37 if not cfg else 5, **cfg)
+    net.load_state_dict(hf.state_dict())
+    net = net.to("cuda").eval()
+    S = cfg.get("image_size", 224)
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(batch, 3, S, S, generator=g)
+    labels = torch.arange(batch) % (37 if not cfg else 5)
+    xr = x.clone().requires_grad_(True)
+    ref_logits = hf(pixel_values=xr).logits
+    F.cross_entropy(ref_logits, labels, reduction="sum").backward()
+    logits, grad = net.input_gradient(x.cuda(), labels.cuda())
+    assert (logits.cpu() - ref_logits.detach()).abs().max().item() < 2e-4 * max(1.0, ref_logits.abs().max().item())
+    scale = xr.grad.abs().max().item()
+    err = (grad.cpu() - xr.grad).abs().max().item()
+    print("vit input gradient: max", scale, "err", err)
+    assert err < 1e-3 * scale, (err, scale)
+    _, again = net.input_gradient(x.cuda(), labels.cuda())
+    assert torch.equal(again, grad)
+    _, one = net.input_gradient(x[1:2].cuda(), labels[1:2].cuda())
+    assert (one[0] - grad[1]).abs().max().item() < 1e-6 * scale + 1e-12
+
+
+def test_vit_victim_drives_the_gradient_attack():
+    """apply_shadow(classifier=ViTVictim) (train_shadow.py:242-266 with config 4's victim): the composite stays within epsilon * mask of the
+    closed-form shadow and differs from it; fp16 (config 4's dtype) agrees with fp32 in the sign of most gradient components."""
+    from advshadow_amd.victims import ViTVictim
+    from oracle import victims as ov
+    cfg = dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=4, intermediate_size=256, patch_size=8, image_size=64)
+    hf = ov.hf_vit(5, seed=3, **cfg)
+    nets = {}
+    for dt in ("fp32", "fp16"):
+        v = ViTVictim(5, compute_dtype=dt, **cfg)
+        v.load_state_dict(hf.state_dict())
+        nets[dt] = v.to("cuda").eval()
+    g = torch.Generator().manual_seed(6)
+    img = torch.rand(3, 64, 64, generator=g)
+    fm = (torch.rand(1, 64, 64, generator=g) > 0.3).float()
+    plain = shadow.apply_shadow(img, (30.0, 34.0), 14.0, fm, None, None, "cuda").cpu()
+    adv = shadow.apply_shadow(img, (30.0, 34.0), 14.0, fm, nets["fp32"], torch.tensor([2]), "cuda").cpu()
+    assert (adv - plain).abs().max().item() <= 0.01 + 1e-6 and not torch.equal(adv, plain)
+    x = torch.rand(2, 3, 64, 64, generator=g).cuda()
+    lab = torch.tensor([1, 4]).cuda()
+    _, g32 = nets["fp32"].input_gradient(x, lab)
+    _, g16 = nets["fp16"].input_gradient(x, lab)
+    big = g32.abs() > 0.05 * g32.abs().max()
+    assert (torch.sign(g16[big]) == torch.sign(g32[big])).float().mean().item() > 0.98

@@ -26,10 +26,13 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--dtype", default="fp32")
     ap.add_argument("--cpu-images", type=int, default=0)
-    ap.add_argument("--victim", default="resnet50", choices=["resnet50", "vgg16"])
+    ap.add_argument("--victim", default="resnet50", choices=["resnet50", "vgg16", "vit"])
     a = ap.parse_args()
     torch.manual_seed(0)
-    if a.victim == "vgg16":
+    if a.victim == "vit":
+        from advshadow_amd.victims import ViTVictim
+        net = ViTVictim(37, compute_dtype=a.dtype).to("cuda").eval()
+    elif a.victim == "vgg16":
         from advshadow_amd.victims import VGG
         net = VGG(16, 37, compute_dtype=a.dtype).to("cuda").eval()
     else:
@@ -48,7 +51,7 @@ def main():
     dt = (time.perf_counter() - t0) / reps
     eng = net.grad_engine(a.batch, a.size)
     tot = bench.conv_profile(eng)
-    rec = {"workload": "iterative-gradient attack on " + ("VGG16" if a.victim == "vgg16" else "ResNet-50"), "size": a.size, "batch": a.batch, "iterations": a.iters,
+    rec = {"workload": "iterative-gradient attack on " + {"vgg16": "VGG16", "vit": "ViT-B/16", "resnet50": "ResNet-50"}[a.victim], "size": a.size, "batch": a.batch, "iterations": a.iters,
            "dtype": a.dtype, "images_per_s": a.batch / dt, "s_per_batch": dt,
            "fwd_bwd_ms_by_kernel": {k: round(v[1], 3) for k, v in sorted(tot.items())},
            "fwd_bwd_ms_total": round(sum(v[1] for v in tot.values()), 3)}
