@@ -10,6 +10,7 @@
 //
 // FLOPs per launch: 4 * B * heads * N^2 * d.
 #include "common.h"
+#include <stdlib.h>
 
 #define AT_THREADS 256
 #define KT 64          // keys per tile
@@ -264,6 +265,251 @@ attn_kernel(const AttnP p) {
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Second-generation kernel for 16-bit storage without a score bias (every attention of the two UNet lineages and of the ViT
+// victims).  The first kernel is VALU-bound on the softmax -- per score one FMA (scale, subtract the row max), one v_exp, one add
+// (row sum), one max, half a pack: ~22 issue cycles per 64 scores against 6..12 MFMAs per 64-key tile -- most of all at the small
+// head widths of the class-conditional UNet (d = 16 at N = 65 536: 86 % of that network's FLOPs).  Here
+//   * q is pre-multiplied by log2(e) / sqrt(d) once, and the running row maximum enters the score MFMA as its INITIAL accumulator
+//     (-m), so a score leaves the matrix core ready for v_exp: no per-score FMA;
+//   * the maximum lags: a tile is rescaled only when some score exceeds the running maximum by more than 2^8 (T13 of the CDNA
+//     guide; P stays <= 256, exact in the f32 accumulators, 8 significant bits in the 16-bit P operand either way);
+//   * where the head width leaves spare rows in the 32-row V^T tile (d % 32 != 0), one of them is all ones and the row sum comes
+//     out of the P.V product, rescaling included: no per-score add;
+//   * keys are staged SUB 64-key tiles at a time: one barrier pair per 64 * SUB keys instead of per 64.
+// Exact softmax algebra otherwise (online rescaling, masked padding keys).  FLOPs per launch: 4 * B * heads * N^2 * d.
+template <typename T, int DT, int SUB>
+__global__ void __launch_bounds__(AT_THREADS, 2)
+attn2_kernel(const AttnP p) {
+    constexpr int ESZ = 2;
+    constexpr int KTS = KT * SUB;                 // keys staged per barrier pair
+    constexpr int DMAX = DT * 32;
+    constexpr int KS = DMAX * ESZ + 16;           // K tile row stride (bytes), padded
+    constexpr int VS = KTS * ESZ + 8;             // V^T tile row stride (bytes)
+    constexpr int QSTEPS = DMAX * ESZ / 32;
+    constexpr float THR = 8.0f;
+    extern __shared__ __attribute__((aligned(16))) char sm[];     // KTS*KS + DMAX*VS bytes
+    char* sK = sm;
+    char* sV = sm + KTS * KS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int b = blockIdx.z, hd = blockIdx.y;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const bool active = q0 < p.N;
+    const int d = p.d;
+    const int dbytes = d * ESZ;
+    const int dsteps = (dbytes + 31) / 32;
+    const size_t rowb = (size_t)p.ld * ESZ;
+    const char* base = p.qkv + (size_t)b * p.N * rowb;
+    const char* qp = base + (size_t)(p.q_off + hd * p.head_stride) * ESZ;
+    const char* kp = base + (size_t)(p.k_off + hd * p.head_stride) * ESZ;
+    const char* vp = base + (size_t)(p.v_off + hd * p.head_stride) * ESZ;
+    const bool ones_row = (d & 31) != 0;          // V^T row d of the last tile is all ones: O^T row d = the softmax denominator
+
+    // Q fragments, pre-scaled: lane (query l31, half lh) holds bytes [32*s + 16*lh, +16) of its query row
+    u32x4 qf[QSTEPS];
+#pragma unroll
+    for (int s = 0; s < QSTEPS; ++s) {
+        qf[s] = u32x4{0, 0, 0, 0};
+        if (q0 + l31 < p.N && s * 32 + lh * 16 < dbytes) {
+            const u32x4 raw = *(const u32x4*)(qp + (size_t)(q0 + l31) * rowb + s * 32 + lh * 16);
+            float f[8];
+            unpack16<T>(raw, f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] *= p.scale_log2e;
+            qf[s] = pack16<T>(f);
+        }
+    }
+    f32x16 o[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    float m_run = 0.f, l_run = 0.f;
+    bool first = true;
+
+    const int cpr = dbytes / 16, cprp = dsteps * 2;
+    const int nvec = KTS * cprp;
+    constexpr int NV = (KTS * DMAX * ESZ / 16 + AT_THREADS - 1) / AT_THREADS;       // K vectors per thread per stage
+    constexpr int NQ = ((KTS / 4) * (DMAX * ESZ / 16) + AT_THREADS - 1) / AT_THREADS; // V key-quads per thread per stage
+    u32x4 kreg[NV], vreg[NQ][4];
+    const int nquad = (KTS / 4) * cpr;
+    int k_key[NV], k_goff[NV], k_loff[NV], v_key0[NQ], v_goff[NQ], v_loff[NQ];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = tid + i * AT_THREADS, key = v / cprp, ch = v - key * cprp;
+        k_key[i] = v < nvec ? (ch < cpr ? key : key | 0x40000000) : -1;
+        k_goff[i] = ch * 16;
+        k_loff[i] = key * KS + ch * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const int v = tid + i * AT_THREADS, kq = v / cpr, ch = v - kq * cpr;
+        v_key0[i] = v < nquad ? 4 * kq : -1;
+        v_goff[i] = ch * 16;
+        v_loff[i] = (ch * 8) * VS + kq * 8;
+    }
+    if (ones_row) {                               // the commit below never touches rows >= d
+        T t1; Elt<T>::st(&t1, 1.0f);
+        const unsigned short one = t1.v;
+        for (int k = tid; k < KTS; k += AT_THREADS) *(unsigned short*)(sV + (size_t)d * VS + k * 2) = one;
+    }
+    auto fetch = [&](int k0) {
+        const bool edge = k0 + KTS > p.N;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            kreg[i] = u32x4{0, 0, 0, 0};
+            const int key = k_key[i];
+            if (key >= 0 && !(key & 0x40000000) && (!edge || k0 + key < p.N))
+                kreg[i] = *(const u32x4*)(kp + (size_t)(k0 + key) * rowb + k_goff[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < NQ; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int key = v_key0[i] + j;
+                vreg[i][j] = (v_key0[i] >= 0 && (!edge || k0 + key < p.N)) ? *(const u32x4*)(vp + (size_t)(k0 + key) * rowb + v_goff[i])
+                                                                            : u32x4{0, 0, 0, 0};
+            }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (k_key[i] >= 0) *(u32x4*)(sK + k_loff[i]) = kreg[i];
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            if (v_key0[i] < 0) continue;
+            char* dst = sV + v_loff[i];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const unsigned lo01 = __builtin_amdgcn_perm(vreg[i][1][w], vreg[i][0][w], 0x05040100u);
+                const unsigned lo23 = __builtin_amdgcn_perm(vreg[i][3][w], vreg[i][2][w], 0x05040100u);
+                const unsigned hi01 = __builtin_amdgcn_perm(vreg[i][1][w], vreg[i][0][w], 0x07060302u);
+                const unsigned hi23 = __builtin_amdgcn_perm(vreg[i][3][w], vreg[i][2][w], 0x07060302u);
+                *(u32x2*)(dst + (2 * w) * VS) = u32x2{lo01, lo23};
+                *(u32x2*)(dst + (2 * w + 1) * VS) = u32x2{hi01, hi23};
+            }
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < p.n_valid; k0 += KTS) {
+        __syncthreads();
+        commit();
+        __syncthreads();
+        if (k0 + KTS < p.n_valid) fetch(k0 + KTS);
+        if (!active) continue;
+#pragma unroll
+        for (int sub = 0; sub < SUB; ++sub) {
+            const int kt0 = k0 + sub * KT;
+            if (kt0 >= p.n_valid) break;                       // wave-uniform
+            // ---- S'^T = K (s q)^T - m for the two 32-key blocks (m = 0 before the first tile)
+            f32x16 st[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[kb][r] = -m_run;
+#pragma unroll
+                for (int s = 0; s < QSTEPS; ++s)
+                    if (s == 0 || s < dsteps) {
+                        const u32x4 kf = *(const u32x4*)(sK + (sub * KT + kb * 32 + l31) * KS + s * 32 + lh * 16);
+                        st[kb] = mma16<T>(kf, qf[s], st[kb]);
+                    }
+            }
+            if (kt0 + KT > p.n_valid) {                          // only the last tile can hold padded keys (wave-uniform)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (kt0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh >= p.n_valid) st[kb][r] = -INFINITY;
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) mx = fmaxf(mx, fmaxf(st[kb][r], st[kb][r + 1]));      // v_max3_f32
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            if (first || __any(mx > THR)) {                    // wave-uniform: raise the running maximum, rescale what was accumulated
+                const float up = first ? mx : fmaxf(mx, 0.f);
+                const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-up);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) st[kb][r] -= up;
+                l_run *= alpha;
+#pragma unroll
+                for (int t = 0; t < DT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+                m_run += up;
+                first = false;
+            }
+            float ls = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    st[kb][r] = __builtin_amdgcn_exp2f(st[kb][r]);
+                    if (!ones_row) ls += st[kb][r];
+                }
+            l_run += ls;
+            // ---- O^T += V^T P^T ; P^T registers are the B operand as they stand
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    u32x4 pf;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) pf[w] = pack2<T>(st[kb][8 * s2 + 2 * w], st[kb][8 * s2 + 2 * w + 1]);
+#pragma unroll
+                    for (int t = 0; t < DT; ++t) {
+                        const char* vr = sV + (t * 32 + l31) * VS + (sub * KT + kb * 32 + 16 * s2 + 4 * lh) * 2;
+                        const u32x2 lo = *(const u32x2*)vr;
+                        const u32x2 hi = *(const u32x2*)(vr + 16);
+                        o[t] = mma16<T>(u32x4{lo[0], lo[1], hi[0], hi[1]}, pf, o[t]);
+                    }
+                }
+        }
+    }
+    if (!active || q0 + l31 >= p.N) return;
+    float l_tot;
+    if (ones_row) {                                            // row d of O^T: register r of lane half lh with (r&3) + 8(r>>2) + 4 lh = d % 32
+        const int dr = d & 31, t = d >> 5;
+        float v = 0.f;
+#pragma unroll
+        for (int tt = 0; tt < DT; ++tt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (tt == t && (r & 3) + 8 * (r >> 2) + 4 * lh == dr) v = o[tt][r];
+        l_tot = v + __shfl_xor(v, 32);                          // only one lane half holds the row: the other contributes 0
+    } else {
+        l_tot = l_run + __shfl_xor(l_run, 32);
+    }
+    const float inv = 1.0f / l_tot;
+    T* orow = (T*)p.out + ((size_t)b * p.N + q0 + l31) * (size_t)(p.heads * d) + hd * d;
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int di = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (di < d) Elt<T>::st(orow + di, o[t][r] * inv);
+        }
+}
+
+template <typename T, int DT, int SUB>
+static int attn2_launch(const AttnP& p, hipStream_t st) {
+    constexpr size_t lds = (size_t)KT * SUB * (DT * 32 * 2 + 16) + (size_t)DT * 32 * (KT * SUB * 2 + 8);
+    static bool attr_set = false;
+    if (!attr_set) {
+        ADVS_HIP(hipFuncSetAttribute((const void*)attn2_kernel<T, DT, SUB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    dim3 grid(cdiv(p.N, 128), p.heads, p.B);
+    attn2_kernel<T, DT, SUB><<<grid, AT_THREADS, lds, st>>>(p);
+    ADVS_CHECK_LAUNCH("attention");
+    return ADVS_OK;
+}
+
 template <typename T, int DT>
 static int attn_launch_dt(const AttnP& p, hipStream_t st) {
     constexpr int ESZ = AMma<T>::ESZ;
@@ -281,6 +527,13 @@ static int attn_launch_dt(const AttnP& p, hipStream_t st) {
 
 template <typename T>
 static int attn_launch(const AttnP& p, hipStream_t st) {
+    if constexpr (sizeof(T) == 2) {
+        static const bool old_kernel = getenv("ADVS_ATTN_V1") != nullptr;      // A/B knob for tools/
+        if (!p.bias && p.d <= 64 && !old_kernel) {
+            if (p.d <= 32) return attn2_launch<T, 1, 4>(p, st);
+            return attn2_launch<T, 2, 2>(p, st);
+        }
+    }
     switch ((p.d + 31) / 32) {
         case 1: return attn_launch_dt<T, 1>(p, st);
         case 2: return attn_launch_dt<T, 2>(p, st);
