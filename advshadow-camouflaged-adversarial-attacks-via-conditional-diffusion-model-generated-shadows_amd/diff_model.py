@@ -247,9 +247,9 @@ class UNetModel(nn.Module):
 class _ForwardEngine:
     """The frozen plan of one UNetModel forward for (batch, size, dtype)."""
 
-    def __init__(self, model, W, batch, size, dt):
+    def __init__(self, model, W, batch, size, dt, stream=None):
         dev = next(model.parameters()).device
-        self.stream = torch.cuda.Stream(device=dev)
+        self.stream = stream if stream is not None else torch.cuda.Stream(device=dev)
         self.model, self.B, self.S, self.dt = model, batch, size, dt
         with torch.cuda.device(dev):
             bld = Builder(dev, dt, self.stream, batch)

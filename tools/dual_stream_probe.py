@@ -18,14 +18,19 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--priority", action="store_true", help="first half on a high-priority stream, second on a low-priority one")
+    ap.add_argument("--eager", action="store_true")
     a = ap.parse_args()
     torch.manual_seed(0)
-    net = dm.UNetModel(compute_dtype="bf16").to("cuda").eval()
+    net = dm.UNetModel(compute_dtype="bf16", use_graph=not a.eager).to("cuda").eval()
     dt = dm.dtype_code("bf16")
     W = net.packed_weights(dt)
     full = dm._ForwardEngine(net, W, a.batch, a.size, dt)
-    h1 = dm._ForwardEngine(net, W, a.batch // 2, a.size, dt)
-    h2 = dm._ForwardEngine(net, W, a.batch // 2, a.size, dt)
+    lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
+    s1 = torch.cuda.Stream(priority=hi) if a.priority else None
+    s2 = torch.cuda.Stream(priority=lo) if a.priority else None
+    h1 = dm._ForwardEngine(net, W, a.batch // 2, a.size, dt, stream=s1)
+    h2 = dm._ForwardEngine(net, W, a.batch // 2, a.size, dt, stream=s2)
     for e in (full, h1, h2):
         e.x.normal_()
         e.t.fill_(501)
