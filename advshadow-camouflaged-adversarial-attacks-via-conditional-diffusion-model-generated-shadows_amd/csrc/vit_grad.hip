@@ -221,12 +221,21 @@ static int attn_bwd_launch(const void* qkv, const void* out, const void* d_out, 
     ADVS_CHECK_LAUNCH("attention_bwd (keys)");
     return ADVS_OK;
 }
+// 16-bit dtypes: the MFMA kernels of attention_bwd.hip
+int attn_bwd_mfma(const void* qkv, const void* out, const void* d_out, void* d_qkv, void* scratch, int b, int n, int n_valid, int heads,
+                  int d, int ld, int q_off, int k_off, int v_off, int head_stride, int dtype, hipStream_t st);
+
 extern "C" int advs_attention_bwd(const void* qkv, const void* out, const void* d_out, void* d_qkv, void* scratch, int b, int n,
                                   int n_valid, int heads, int d, int ld, int q_off, int k_off, int v_off, int head_stride, int dtype,
                                   void* stream) {
     ADVS_REQUIRE(dtype_ok(dtype), "advs_attention_bwd: unknown dtype code %d", dtype);
     ADVS_REQUIRE(qkv && out && d_out && d_qkv && scratch && b > 0 && n > 0 && n_valid > 0 && n_valid <= n && heads > 0, "attention_bwd: bad args");
     ADVS_REQUIRE(d > 0 && d <= 64, "attention_bwd: d=%d must be in 1..64", d);
+    static const bool valu_only = getenv("ADVS_ATTN_BWD_V1") != nullptr;          // A/B knob for tools/
+    if (dtype != ADVS_F32 && !valu_only && d % 8 == 0 && ld % 8 == 0 && q_off % 8 == 0 && k_off % 8 == 0 && v_off % 8 == 0 &&
+        head_stride % 8 == 0)
+        return attn_bwd_mfma(qkv, out, d_out, d_qkv, scratch, b, n, n_valid, heads, d, ld, q_off, k_off, v_off, head_stride, dtype,
+                             (hipStream_t)stream);
     float* sP = (float*)scratch;
     float* sdS = sP + (size_t)b * heads * n * n;
     if (d <= 32) ADVS_SWITCH_T(dtype, return (attn_bwd_launch<T, 32>(qkv, out, d_out, d_qkv, sP, sdS, b, n, n_valid, heads, d, ld, q_off, k_off, v_off, head_stride, (hipStream_t)stream)));

@@ -237,8 +237,10 @@ int advs_layernorm_bwd(const void* dy, const void* x, const float* gamma, const 
 int advs_gelu(const void* x, void* y, long long n, int dtype, void* stream);
 int advs_gelu_bwd(const void* x, const void* dy, void* dx, long long n, int dtype, void* stream);
 /* Gradient of advs_attention_masked: qkv / d_qkv laid out as there, out = the forward's output, d_out its gradient ([b][n][heads*d]);
- * d <= 64, keys and head width small enough for 2 * n_valid * d f32 in LDS (ViT-B/16: 197 x 64).  scratch:
- * advs_attention_bwd_scratch_bytes(b, n, heads) bytes ([2][b][heads][n][n] f32: P and dS, transposed).                            */
+ * d <= 64.  16-bit dtypes with d and every offset a multiple of 8: two MFMA kernels that recompute the scores (csrc/attention_bwd.hip,
+ * any n); otherwise (f32: the parity path) f32 VALU kernels that need 2 * n_valid * d f32 in LDS (ViT-B/16: 197 x 64).  scratch:
+ * advs_attention_bwd_scratch_bytes(b, n, heads) bytes (f32 path: [2][b][heads][n][n] P and dS, transposed; MFMA path: the first
+ * [2][b][heads][n] floats, row log-sum-exp and D = dO . O).                                                                       */
 size_t advs_attention_bwd_scratch_bytes(int b, int n, int heads);
 int advs_attention_bwd(const void* qkv, const void* out, const void* d_out, void* d_qkv, void* scratch, int b, int n,
                        int n_valid, int heads, int d, int ld, int q_off, int k_off, int v_off, int head_stride, int dtype,
