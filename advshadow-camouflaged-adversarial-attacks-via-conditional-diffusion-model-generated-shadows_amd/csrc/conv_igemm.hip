@@ -313,6 +313,8 @@ static int conv_launch(ConvKP& p, hipStream_t st) {
 static int pick_tile(long long m_img, int cout);
 bool conv_halo_eligible(const ConvKP& p);
 int conv_halo_dispatch(ConvKP& p, int dtype, hipStream_t st);
+bool conv_halo512_eligible(const ConvKP& p, int dtype);
+int conv_halo512_dispatch(ConvKP& p, int dtype, hipStream_t st);
 int conv_halo_subpixel_dispatch(ConvKP& p, int dtype, hipStream_t st);
 bool conv_halo_extra_eligible(const ConvKP& p);
 int conv_halo_extra_dispatch(ConvKP& p, int dtype, hipStream_t st);
@@ -362,6 +364,11 @@ static int resolve_tile(const advs_conv_args* a, long long m_img) {
     if (a->tile) return a->tile;
     // (with a fused 1x1 operand tile 10 becomes 13: the same kernel with one-tap units behind the 3x3 slabs, +3 %)
     static const bool no_halo_extra = getenv("ADVS_NO_HALO_EXTRA") != nullptr;      // A/B knob for tools/
+    // 14: the 512-pixel halo kernel (conv_halo512.hip), from 128 x 128 images up (a rule on ONE image's size, see pick_tile)
+    static const bool halo512 = getenv("ADVS_HALO512") != nullptr;
+    if (halo512 && a->dtype != ADVS_F32 && a->ksize == 3 && a->stride == 1 && a->pad == 1 && !a->upsample && !a->e1 && a->h % 16 == 0 &&
+        a->w_ % 32 == 0 && m_img >= 128 * 128)
+        return 14;
     if (a->ksize == 3 && a->stride == 1 && a->pad == 1 && !a->upsample && (!a->e1 || !no_halo_extra) && a->h % 16 == 0 && a->w_ % 16 == 0)
         return 10;
     return pick_tile(m_img, a->cout);
@@ -375,7 +382,7 @@ extern "C" int advs_conv_resolve_tile(const advs_conv_args* a) {
     return resolve_tile(a, ho * wo);
 }
 extern "C" int advs_conv_tile_rows(int tile) {
-    switch (tile) { case 1: case 2: case 5: case 6: case 8: case 10: case 12: case 13: return 64; case 3: case 4: case 7: case 9: return 128; default: return 0; }
+    switch (tile) { case 1: case 2: case 5: case 6: case 8: case 10: case 12: case 13: return 64; case 3: case 4: case 7: case 9: case 14: return 128; default: return 0; }
 }
 
 extern "C" int advs_conv2d(const advs_conv_args* a, void* stream) {
@@ -434,6 +441,11 @@ extern "C" int advs_conv2d(const advs_conv_args* a, void* stream) {
     p.dHoWo.init((unsigned)(p.Ho * p.Wo)); p.dWo.init((unsigned)p.Wo);
     int tile = resolve_tile(a, (long long)p.Ho * p.Wo);
     if (tile == 10 && conv_halo_extra_eligible(p)) tile = 13;   // 13: the halo kernel with the fused 1x1 operand
+    if (tile == 14 && !conv_halo512_eligible(p, a->dtype)) {
+        ADVS_REQUIRE(g_tile_override != 0, "conv2d: tile 14 (512-pixel halo kernel) needs a 16-bit dtype, 3x3 stride 1 pad 1, no upsample / extra operand, H a multiple of 16 and W of 32");
+        tile = 10;                                           // tuning override on a shape it cannot take
+        if (conv_halo_extra_eligible(p)) tile = 13;
+    }
     if (tile == 10 && !conv_halo_eligible(p)) {
         ADVS_REQUIRE(g_tile_override != 0, "conv2d: tile 10 (halo kernel) needs 3x3 stride 1 pad 1, no upsample / extra operand, H and W multiples of 16");
         tile = pick_tile((long long)p.Ho * p.Wo, a->cout);   // tuning override on a shape the halo kernel cannot take
@@ -446,11 +458,12 @@ extern "C" int advs_conv2d(const advs_conv_args* a, void* stream) {
         else ADVS_REQUIRE(a->stats_rows == wm, "conv2d: stats buffer sized for %d-row blocks but the tile uses %d", a->stats_rows, wm);
     }
     // the halo kernels' fast epilogue (conv_common.h): 16-bit storage, nothing but bias / time embedding / statistics around the GEMM
-    p.fast_epi = (tile == 10 || tile == 12 || tile == 13) && a->dtype != ADVS_F32 && !a->residual && !a->relu_mask &&
+    p.fast_epi = (tile == 10 || tile == 12 || tile == 13 || tile == 14) && a->dtype != ADVS_F32 && !a->residual && !a->relu_mask &&
                  a->act == ADVS_ACT_NONE && getenv("ADVS_NO_FAST_EPILOGUE") == nullptr;
     if (tile == 12) return conv_halo_subpixel_dispatch(p, a->dtype, (hipStream_t)stream);
     if (tile == 13) return conv_halo_extra_dispatch(p, a->dtype, (hipStream_t)stream);
     if (tile == 10) return conv_halo_dispatch(p, a->dtype, (hipStream_t)stream);
+    if (tile == 14) return conv_halo512_dispatch(p, a->dtype, (hipStream_t)stream);
     ADVS_SWITCH_T(a->dtype, return conv_dispatch<T>(p, tile, (hipStream_t)stream));
     return ADVS_ERR_ARG;                    // not reached
 }

@@ -41,16 +41,20 @@ CONV_CASES = [
     (2, 16, 16, 64, 128, 128, 3, 1, 0, 1, 1, 1, None),     # halo-eligible: concat, full epilogue
     (1, 48, 32, 128, 0, 256, 3, 1, 0, 1, 0, 0, "silu"),    # halo-eligible: 3x2 pixel tiles, 2 channel tiles
     (3, 16, 32, 64, 0, 64, 3, 1, 0, 0, 1, 0, None),        # halo-eligible: batch 3, N tail (64 < 128), 1 slab
+    (2, 16, 32, 64, 128, 128, 3, 1, 0, 1, 1, 1, None),     # 512-pixel halo tile: concat (2 + 4 half slabs), full epilogue
+    (1, 32, 64, 128, 0, 128, 3, 1, 0, 1, 1, 0, None),      # 512-pixel halo tile: 2x2 pixel tiles, the fast epilogue's shape
 ]
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 14])
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv2d(case, dt, tile):
     B, H, W, C1, C2, Cout, k, stride, ups, has_b, has_t, has_r, act = case
     if tile == 10 and not (k == 3 and stride == 1 and not ups and H % 16 == 0 and W % 16 == 0):
         pytest.skip("halo kernel: 3x3 stride 1, H and W multiples of 16")
+    if tile == 14 and not (k == 3 and stride == 1 and not ups and H % 16 == 0 and W % 32 == 0 and dt != "fp32"):
+        pytest.skip("512-pixel halo kernel: 16-bit, 3x3 stride 1, H a multiple of 16, W of 32")
     pad = 1 if k == 3 else 0
     x1 = rnd(B, C1, H, W, seed=1)
     x2 = rnd(B, C2, H, W, seed=2) if C2 else None
@@ -391,11 +395,13 @@ def test_groupnorm_chan_add(dt):
 
 # ------------------------------------------------------------------------------ GN statistics from the conv epilogue
 @pytest.mark.parametrize("dt", DTS)
-@pytest.mark.parametrize("tiles", [(1, 1), (4, 1), (1, 4), (3, 5), (10, 1)])
+@pytest.mark.parametrize("tiles", [(1, 1), (4, 1), (1, 4), (3, 5), (10, 1), (14, 1)])
 def test_groupnorm_with_epilogue_stats(dt, tiles):
     """conv(+stats) x2 -> GroupNorm(32) over their concat (groups of 12 straddle the sources) must equal
     the unfused path; statistics come from [row block][channel] partials written by the epilogues."""
-    B, H, W = 2, 16, 16
+    if tiles[0] == 14 and dt == "fp32":
+        pytest.skip("512-pixel halo kernel: 16-bit only")
+    B, H, W = 2, 16, 32 if tiles[0] == 14 else 16
     xa, xb = rnd(B, 64, H, W, seed=41), rnd(B, 64, H, W, seed=42)
     wa, wb = rnd(256, 64, 3, 3, seed=43, scale=0.05), rnd(128, 64, 1, 1, seed=44, scale=0.2)
     gamma, beta = rnd(384, seed=45) * 0.3 + 1, rnd(384, seed=46) * 0.1
