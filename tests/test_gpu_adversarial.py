@@ -389,6 +389,31 @@ def test_vit_backward_pieces_match_autograd():
 
 
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("n", [8 * 1000, 8 * 37 + 3])
+def test_gelu_16bit_both_ways(prec, n):
+    """Exact-GELU forward and gradient in 16-bit storage (csrc/vit_grad.hip: the vectorised kernel with the Abramowitz-Stegun erf
+    when n is a multiple of 8, the libm kernel otherwise) against torch on the same rounded inputs: within one ulp of the result."""
+    lib = OneOp(prec, 1).b.lib
+    td = torch.bfloat16 if prec == "bf16" else torch.float16
+    code = 1 if prec == "bf16" else 2
+    s = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(n)
+    x16 = (torch.randn(n, generator=g) * 3).to(td)
+    dy16 = torch.randn(n, generator=g).to(td)
+    x = x16.float().requires_grad_(True)
+    y = F.gelu(x)
+    y.backward(dy16.float())
+    xd, dyd = x16.to(dev()), dy16.to(dev())
+    yd, dxd = torch.empty_like(xd), torch.empty_like(xd)
+    assert lib.advs_gelu(ptr(xd), ptr(yd), n, code, s) == 0 and lib.advs_gelu_bwd(ptr(xd), ptr(dyd), ptr(dxd), n, code, s) == 0
+    torch.cuda.synchronize()
+    ulp = 2.0 ** -8 if prec == "bf16" else 2.0 ** -11
+    for got, ref in ((yd, y.detach()), (dxd, x.grad)):
+        err = (got.float().cpu() - ref).abs()
+        assert (err <= ulp * ref.abs().clamp_min(2.0 ** -6) + 1e-7).all(), err.max().item()
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
 @pytest.mark.parametrize("B,H,d,n,nv", [(2, 3, 24, 64, 50), (2, 2, 32, 128, 65), (3, 12, 64, 256, 197), (1, 2, 64, 200, 200),
                                         (2, 1, 64, 320, 257)])
 def test_attention_backward_mfma_matches_autograd(prec, B, H, d, n, nv):
