@@ -566,8 +566,8 @@ extern "C" int advs_attention(const void* qkv, void* out, int b, int n, int head
     ADVS_REQUIRE(dtype_ok(dtype), "advs_attention: unknown dtype code %d", dtype);
     return attention_impl(qkv, out, b, n, n, heads, d, ld, q_off, k_off, v_off, head_stride, dtype, stream);
 }
-// Same with the token axis padded to a multiple of 64: only the first n_valid tokens are real keys
-// (ViT: 197 tokens in rows of 256); padded query rows produce values nobody reads.
+// Same with the token axis padded (victims.py: to a multiple of 16): only the first n_valid tokens are real keys
+// (ViT: 197 tokens in rows of 208); padded query rows produce values nobody reads.
 extern "C" int advs_attention_masked(const void* qkv, void* out, int b, int n, int n_valid, int heads, int d, int ld,
                                      int q_off, int k_off, int v_off, int head_stride, int dtype, void* stream) {
     ADVS_REQUIRE(dtype_ok(dtype), "advs_attention_masked: unknown dtype code %d", dtype);

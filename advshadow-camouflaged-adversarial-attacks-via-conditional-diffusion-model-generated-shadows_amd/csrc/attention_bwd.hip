@@ -1,5 +1,5 @@
 // Attention backward on the matrix cores, 16-bit dtypes, head width <= 64 (the ViT victim of the gradient attack,
-// victims.py: timm vision_transformer.Attention with fused_attn; 197 tokens in rows of 256, 12 heads of 64).
+// victims.py: timm vision_transformer.Attention with fused_attn; 197 tokens in rows of 208, 12 heads of 64).
 //
 //   S = (s q) k^T,  P = softmax_rows(S),  O = P v.   Given dO:   D_i = dO_i . O_i,   dP = dO v^T,   dS = P o (dP - D),
 //   dq = s dS k,    dk = s dS^T q,    dv = P^T dO                                    (s = 1 / sqrt d).

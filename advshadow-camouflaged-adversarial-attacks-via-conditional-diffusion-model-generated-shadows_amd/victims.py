@@ -348,7 +348,7 @@ class ViTVictim(_InputGradient, nn.Module):
     """ViT-B/16-style classifier with HF's parameter names (``AutoModelForImageClassification`` of
     ASR_fast.py:47-51; config C4 of BASELINE.json), forward on the HIP kernels: patch projection and every
     Linear as implicit-GEMM 1x1 convs (bias / GELU / residual in the epilogue), LayerNorm, flash attention
-    with the 197 tokens padded to 256 rows and the padding masked."""
+    with the 197 tokens padded to 208 rows and the padding masked."""
 
     def __init__(self, num_labels=37, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
                  intermediate_size=3072, patch_size=16, image_size=224, layer_norm_eps=1e-12,
@@ -499,7 +499,7 @@ class _ViTGradEngine:
         C, heads, S, ps, eps = cfg["hidden"], cfg["heads"], cfg["image"], cfg["patch"], cfg["eps"]
         g = S // ps
         npatch, n_tok = g * g, g * g + 1
-        n_pad = (n_tok + 63) // 64 * 64
+        n_pad = (n_tok + 15) // 16 * 16          # rows per image: the GEMMs run over every row, the attention kernels mask keys >= n_tok
         d = C // heads
         rows = batch * n_pad
         with torch.cuda.device(dev):
@@ -593,7 +593,7 @@ class _ViTEngine:
         C, heads, S, ps, eps = cfg["hidden"], cfg["heads"], cfg["image"], cfg["patch"], cfg["eps"]
         g = S // ps
         npatch, n_tok = g * g, g * g + 1
-        n_pad = (n_tok + 63) // 64 * 64
+        n_pad = (n_tok + 15) // 16 * 16          # rows per image: the GEMMs run over every row, the attention kernels mask keys >= n_tok
         d = C // heads
         with torch.cuda.device(dev):
             bld = Builder(dev, dt, self.stream, batch)

@@ -162,7 +162,7 @@ int advs_layernorm(const void* x, const float* gamma, const float* beta, void* y
 int advs_attention(const void* qkv, void* out, int b, int n, int heads, int d, int ld,
                    int q_off, int k_off, int v_off, int head_stride, int dtype, void* stream);
 
-/* Token axis padded (ViT: 197 tokens in rows of 256): keys >= n_valid are masked.  */
+/* Token axis padded (ViT: 197 tokens in rows of 208): keys >= n_valid are masked.  */
 int advs_attention_masked(const void* qkv, void* out, int b, int n, int n_valid, int heads, int d, int ld,
                           int q_off, int k_off, int v_off, int head_stride, int dtype, void* stream);
 
