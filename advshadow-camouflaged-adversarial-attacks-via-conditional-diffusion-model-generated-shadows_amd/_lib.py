@@ -105,6 +105,7 @@ SIGNATURES = {
     "advs_gelu_bwd": [vp, vp, vp, C.c_longlong, i32, vp],
     "advs_attention_bwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "advs_scatter_row0": [vp, vp, i32, C.c_longlong, i32, i32, vp],
+    "advs_scatter_cls_mean": [vp, vp, i32, i32, i32, i32, i32, vp],
     "advs_unpatchify_padded": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "advs_event_record": [vp, vp],
     "advs_event_elapsed_ms": [vp, vp, C.POINTER(f32)],

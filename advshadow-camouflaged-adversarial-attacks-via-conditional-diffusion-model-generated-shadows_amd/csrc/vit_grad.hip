@@ -292,6 +292,24 @@ extern "C" int advs_scatter_row0(const float* src, void* dst, int b, long long r
     ADVS_CHECK_LAUNCH("scatter_row0");
     return ADVS_OK;
 }
+// Gradient of advs_cls_mean_rows_f32 (DINOv2's head input [cls | mean of the patch tokens]): row 0 of image b receives src[b][0..c),
+// rows 1 .. np receive src[b][c..2c) / np each; rows beyond (padding) are left as they are (zero).
+template <typename T>
+__global__ void scatter_cls_mean_kernel(const float* __restrict__ src, T* __restrict__ dst, int B, int n_pad, int np, int C) {
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i >= (long long)B * (np + 1) * C) return;
+    const int c = (int)(i % C);
+    const long long br = i / C;
+    const int r = (int)(br % (np + 1)), b = (int)(br / (np + 1));
+    const float v = r == 0 ? src[(size_t)b * 2 * C + c] : src[(size_t)b * 2 * C + C + c] / (float)np;
+    Elt<T>::st(dst + ((size_t)b * n_pad + r) * C + c, v);
+}
+extern "C" int advs_scatter_cls_mean(const float* src, void* dst, int b, int n_pad, int np, int c, int dtype, void* stream) {
+    ADVS_REQUIRE(dtype_ok(dtype) && src && dst && b > 0 && c > 0 && np > 0 && n_pad > np, "advs_scatter_cls_mean: bad args");
+    ADVS_SWITCH_T(dtype, scatter_cls_mean_kernel<T><<<cdiv((long long)b * (np + 1) * c, 256), 256, 0, (hipStream_t)stream>>>(src, (T*)dst, b, n_pad, np, c));
+    ADVS_CHECK_LAUNCH("scatter_cls_mean");
+    return ADVS_OK;
+}
 // inverse of advs_patchify_padded for gradients: dx[b][c][py*ps+ky][px*ps+kx] = dcols[b][row_off + py*gw + px][(c*ps+ky)*ps+kx],
 // dcols rows `rows_per_image` apart per image and kpad long (the token-gradient layout: row_off = 1 skips the CLS row).
 template <typename T>

@@ -414,7 +414,7 @@ class ViTVictim(_InputGradient, nn.Module):
         W["ln.g"], W["ln.b"] = f32("vit.layernorm.weight"), f32("vit.layernorm.bias")
         W["cls.w"], W["cls.b"] = f32("classifier.weight"), f32("classifier.bias")
         self._packed[dt] = (ver, W)
-        for key in [k for k in self._engines if k[1] == dt]:
+        for key in [k for k in self._engines if k[-1] == dt]:      # (batch, dt) and ("grad", batch, dt)
             del self._engines[key]
         return W
 
@@ -473,8 +473,6 @@ class ViTVictim(_InputGradient, nn.Module):
         """Static plan of forward + backward-to-the-image (d cross_entropy / d pixel_values) for [batch,3,S,S] inputs."""
         if size is not None and size != self.cfg["image"]:
             raise ValueError(f"ViTVictim was built for {self.cfg['image']}x{self.cfg['image']} inputs, not {size}")
-        if self.cfg.get("head") == "cls_mean" or self.cfg.get("layerscale"):
-            raise _lib.AdvsError("no HIP backward plan for this ViT variant (DINOv2 head / LayerScale)")
         dt = dtype_code(dtype if dtype is not None else self.compute_dtype)
         W, G = self.packed_weights(dt), self.packed_grad_weights(dt)
         eng = self._engines.get(("grad", batch, dt))
@@ -535,17 +533,24 @@ class _ViTGradEngine:
                 saved.append((p, tok, qkv, att, h, pre))
                 tok = nxt
             ln = bld.layernorm(tok, W["ln.g"], W["ln.b"], eps)
-            cls = bld.buf((batch, C), torch.float32)
-            plan.add(lib.advs_gather_rows_f32, ptr(ln), ptr(cls), batch, n_pad, C, dt, keep=(ln, cls))
+            cls_mean = cfg.get("head") == "cls_mean"                       # DINOv2: Linear on [cls | mean of the patch tokens]
+            cls = bld.buf((batch, 2 * C if cls_mean else C), torch.float32)
+            if cls_mean:
+                plan.add(lib.advs_cls_mean_rows_f32, ptr(ln), ptr(cls), batch, n_pad, npatch, C, dt, keep=(ln, cls))
+            else:
+                plan.add(lib.advs_gather_rows_f32, ptr(ln), ptr(cls), batch, n_pad, C, dt, keep=(ln, cls))
             bld.free(ln)
             self.logits = bld.linear(cls, W["cls.w"], W["cls.b"])
             # ---- backward
             K = self.logits.shape[1]
             gl = bld.buf((batch, K), torch.float32)
             plan.add(lib.advs_softmax_ce_grad, ptr(self.logits), ptr(self.labels), ptr(gl), batch, K, 1.0, keep=(self.logits, self.labels, gl))
-            gcls = bld.linear(gl, G["cls.wT"], None)                       # [B, C] f32
-            dln = torch.zeros((batch, 1, n_pad, C), dtype=bld.tdt, device=dev)    # rows other than the CLS row stay zero for good
-            plan.add(lib.advs_scatter_row0, ptr(gcls), ptr(dln), batch, n_pad, C, dt, keep=(gcls, dln))
+            gcls = bld.linear(gl, G["cls.wT"], None)                       # [B, C] (or [B, 2C]) f32
+            dln = torch.zeros((batch, 1, n_pad, C), dtype=bld.tdt, device=dev)    # rows the head does not read stay zero for good
+            if cls_mean:
+                plan.add(lib.advs_scatter_cls_mean, ptr(gcls), ptr(dln), batch, n_pad, npatch, C, dt, keep=(gcls, dln))
+            else:
+                plan.add(lib.advs_scatter_row0, ptr(gcls), ptr(dln), batch, n_pad, C, dt, keep=(gcls, dln))
             scratch = torch.empty(lib.advs_attention_bwd_scratch_bytes(batch, n_pad, heads), dtype=torch.uint8, device=dev)
 
             def ln_bwd(dy, x, gamma, add):
@@ -969,7 +974,7 @@ class ConvNeXtVictim(nn.Module):
         W["head.g"], W["head.beta"] = f32("head.norm.weight"), f32("head.norm.bias")
         W["head.w"], W["head.b"] = f32("head.fc.weight"), f32("head.fc.bias")
         self._packed[dt] = (ver, W)
-        for key in [k for k in self._engines if k[1] == dt]:
+        for key in [k for k in self._engines if k[-1] == dt]:      # (batch, dt) and ("grad", batch, dt)
             del self._engines[key]
         return W
 
@@ -1215,7 +1220,7 @@ class SwinVictim(nn.Module):
         W["norm.g"], W["norm.beta"] = f32("norm.weight"), f32("norm.bias")
         W["head.w"], W["head.b"] = f32("head.fc.weight"), f32("head.fc.bias")
         self._packed[dt] = (ver, W)
-        for key in [k for k in self._engines if k[1] == dt]:
+        for key in [k for k in self._engines if k[-1] == dt]:      # (batch, dt) and ("grad", batch, dt)
             del self._engines[key]
         return W
 
@@ -1320,7 +1325,7 @@ class _SwinEngine:
 
 
 # ============================================================================ DINOv2 (HF names)
-class Dinov2Victim(nn.Module):
+class Dinov2Victim(_InputGradient, nn.Module):
     """HF ``Dinov2ForImageClassification`` (the other ``AutoModelForImageClassification`` checkpoint family of
     ASR_fast.py:47-58) on the ViT engine: patch 14, LayerScale after attention and MLP (folded into the projection /
     fc2 weights), position embeddings interpolated bicubically on the host when the checkpoint's grid differs from the
@@ -1403,7 +1408,7 @@ class Dinov2Victim(nn.Module):
         W["ln.g"], W["ln.b"] = f32("dinov2.layernorm.weight"), f32("dinov2.layernorm.bias")
         W["cls.w"], W["cls.b"] = f32("classifier.weight"), f32("classifier.bias")
         self._packed[dt] = (ver, W)
-        for key in [k for k in self._engines if k[1] == dt]:
+        for key in [k for k in self._engines if k[-1] == dt]:      # (batch, dt) and ("grad", batch, dt)
             del self._engines[key]
         return W
 
@@ -1417,6 +1422,48 @@ class Dinov2Victim(nn.Module):
         return eng
 
     forward = ViTVictim.forward
+
+    # ---- backward to the image: the ViT plan with LayerScale folded into the transposed projection / fc2 weights and the
+    # [cls | mean] head run backwards (advs_scatter_cls_mean)
+    def packed_grad_weights(self, dt):
+        ver = self._version()
+        hit = self._packed.get(("grad", dt))
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        self.packed_weights(dt)
+        sd = {k: v.detach() for k, v in self.state_dict().items()}
+        C = self.cfg["hidden"]
+        linT = lambda w: pack_conv_weight(w.float().t().contiguous().reshape(w.shape[1], w.shape[0], 1, 1), dt)
+        G = {}
+        for i in range(self.cfg["layers"]):
+            s, p = f"dinov2.encoder.layer.{i}", f"vit.encoder.layer.{i}"
+            a = s + ".attention.attention."
+            G[p + ".qkvT"] = linT(torch.cat([sd[a + n + ".weight"].float() for n in ("query", "key", "value")], 0))
+            l1, l2 = sd[s + ".layer_scale1.lambda1"].float(), sd[s + ".layer_scale2.lambda1"].float()
+            G[p + ".oT"] = linT(sd[s + ".attention.output.dense.weight"].float() * l1[:, None])
+            G[p + ".fc1T"] = linT(sd[s + ".mlp.fc1.weight"])
+            G[p + ".fc2T"] = linT(sd[s + ".mlp.fc2.weight"].float() * l2[:, None])
+        wp = sd["dinov2.embeddings.patch_embeddings.projection.weight"].float().reshape(C, -1)        # [C, 3*ps*ps]
+        k = wp.shape[1]
+        kpad = -(-k // 64) * 64
+        wt = torch.zeros((kpad, C), dtype=torch.float32, device=wp.device)
+        wt[:k] = wp.t()
+        G["projT"] = pack_conv_weight(wt.reshape(kpad, C, 1, 1), dt)
+        G["cls.wT"] = sd["classifier.weight"].float().t().contiguous()
+        self._packed[("grad", dt)] = (ver, G)
+        return G
+
+    def grad_engine(self, batch, size=None, dtype=None):
+        """Static plan of forward + backward-to-the-image (d cross_entropy / d pixel_values) for [batch,3,S,S] inputs."""
+        if size is not None and size != self.cfg["image"]:
+            raise ValueError(f"Dinov2Victim was built for {self.cfg['image']}x{self.cfg['image']} inputs, not {size}")
+        dt = dtype_code(dtype if dtype is not None else self.compute_dtype)
+        W, G = self.packed_weights(dt), self.packed_grad_weights(dt)
+        eng = self._engines.get(("grad", batch, dt))
+        if eng is None:
+            eng = _ViTGradEngine(self, W, G, batch, dt)
+            self._engines[("grad", batch, dt)] = eng
+        return eng
 
 
 # ============================================================================ EfficientNetV2-S (torchvision names)
@@ -1523,7 +1570,7 @@ class EfficientNetV2S(nn.Module):
                 gemm(p + ".block.3", p + ".c3")
         W["cls.w"], W["cls.b"] = sd["classifier.1.weight"].float().contiguous(), sd["classifier.1.bias"].float().contiguous()
         self._packed[dt] = (ver, W)
-        for key in [k for k in self._engines if k[1] == dt]:
+        for key in [k for k in self._engines if k[-1] == dt]:      # (batch, dt) and ("grad", batch, dt)
             del self._engines[key]
         return W
 

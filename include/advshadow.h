@@ -248,6 +248,9 @@ int advs_attention_bwd(const void* qkv, const void* out, const void* d_out, void
                        void* stream);
 /* dst[b * row_stride][0..c) = src[b][0..c) (f32 -> compute dtype): the classifier head's gradient enters the CLS row.          */
 int advs_scatter_row0(const float* src, void* dst, int b, long long row_stride, int c, int dtype, void* stream);
+/* Gradient of advs_cls_mean_rows_f32 (the DINOv2 head input, ASR_fast.py:47-58 with a Dinov2 checkpoint): dst[b][0][:] = src[b][0..c),
+ * dst[b][1..np][:] = src[b][c..2c) / np; src f32 [b][2c], dst [b][n_pad][c] in the compute dtype, other rows untouched.            */
+int advs_scatter_cls_mean(const float* src, void* dst, int b, int n_pad, int np, int c, int dtype, void* stream);
 /* Inverse of advs_patchify_padded for gradients: image gradient (NCHW f32) from the patch-column gradients, which sit in rows
  * row_off + patch index of a [b][rows_per_image][kpad] matrix (the token layout: row_off = 1 skips the CLS row).               */
 int advs_unpatchify_padded(const void* dcols, float* dx_nchw, int b, int cin, int h, int w, int patch, int kpad,

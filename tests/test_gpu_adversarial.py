@@ -490,6 +490,33 @@ def test_vit_input_gradient_matches_transformers_autograd(cfg, batch):
     assert (one[0] - grad[1]).abs().max().item() < 1e-6 * scale + 1e-12
 
 
+@pytest.mark.parametrize("size,prec,bound", [(56, "fp32", 1e-3), (112, "fp32", 1e-3), (56, "bf16", 0.08), (56, "fp16", 0.02)])
+def test_dinov2_input_gradient_matches_transformers_autograd(size, prec, bound):
+    """d cross_entropy / d pixel_values of the DINOv2 victim (LayerScale folded into the transposed weights, the [cls | mean] head
+    run backwards by advs_scatter_cls_mean, position embeddings interpolated from a 4x4 grid at 112 px) against autograd over
+    the installed transformers Dinov2ForImageClassification: fp32 within 1e-3 of the largest component, the 16-bit modes within
+    their bound; replays bit-identical."""
+    from advshadow_amd.victims import Dinov2Victim
+    from oracle import victims as ov
+    cfg = dict(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, patch_size=14, mlp_ratio=4)
+    hf = ov.hf_dinov2(5, seed=9, image_size=56, **cfg)
+    net = Dinov2Victim(5, hidden_size=64, num_hidden_layers=2, num_attention_heads=4, image_size=size, pos_grid=4, compute_dtype=prec)
+    net.load_state_dict(hf.state_dict())
+    net = net.to("cuda").eval()
+    x = torch.rand(3, 3, size, size, generator=torch.Generator().manual_seed(21))
+    labels = torch.tensor([0, 3, 4])
+    xr = x.clone().requires_grad_(True)
+    ref_logits = hf(pixel_values=xr).logits
+    F.cross_entropy(ref_logits, labels, reduction="sum").backward()
+    logits, grad = net.input_gradient(x.cuda(), labels.cuda())
+    scale = xr.grad.abs().max().item()
+    err = (grad.cpu() - xr.grad).abs().max().item()
+    print("dinov2 input gradient:", size, prec, "max", scale, "err", err)
+    assert err < bound * scale, (err, scale)
+    _, again = net.input_gradient(x.cuda(), labels.cuda())
+    assert torch.equal(again, grad)
+
+
 def test_vit_victim_drives_the_gradient_attack():
     """apply_shadow(classifier=ViTVictim) (train_shadow.py:242-266 with config 4's victim): the composite stays within epsilon * mask of the
     closed-form shadow and differs from it; fp16 (config 4's dtype) agrees with fp32 in the sign of most gradient components."""
