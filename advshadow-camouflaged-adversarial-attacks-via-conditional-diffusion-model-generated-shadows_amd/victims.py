@@ -898,7 +898,7 @@ def convnext_canonical_state_dict(sd):
     return out
 
 
-class ConvNeXtVictim(nn.Module):
+class ConvNeXtVictim(_InputGradient, nn.Module):
     """``timm.create_model('convnext_base.fb_in1k', num_classes=37)`` (ASR_fast.py:21-26) on the HIP kernels.
     Parameter names follow timm (``stem.{0,1}``, ``stages.i.downsample.{0,1}``, ``stages.i.blocks.j.{conv_dw,norm,
     mlp.fc1,mlp.fc2,gamma}``, ``head.norm``, ``head.fc``); HF ConvNext names are accepted by load_state_dict.
@@ -987,6 +987,42 @@ class ConvNeXtVictim(nn.Module):
             self._engines[(batch, dt)] = eng
         return eng
 
+    # ---- backward to the image (the gradient attack of tools/train_shadow.py:177-221 with this victim) ------------------
+    def packed_grad_weights(self, dt):
+        """Every Linear / patch GEMM weight transposed (its data gradient is a GEMM against W), layer scale folded as forwards."""
+        ver = self._version()
+        hit = self._packed.get(("grad", dt))
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        self.packed_weights(dt)
+        sd = {k: v.detach() for k, v in self.state_dict().items()}
+        linT = lambda w: pack_conv_weight(w.float().t().contiguous().reshape(w.shape[1], w.shape[0], 1, 1), dt)
+        G = {"stemT": linT(sd["stem.0.weight"].float().reshape(self.dims[0], -1)),                  # [48][C0]
+             "head.wT": sd["head.fc.weight"].float().t().contiguous()}
+        for i, (n, c) in enumerate(zip(self.depths, self.dims)):
+            if i > 0:
+                p = f"stages.{i}.downsample"
+                # forward weight [cout][dy][dx][cin] (the channel order of advs_space_to_depth2) -> [4 cin][cout]
+                G[p + ".wT"] = linT(sd[p + ".1.weight"].float().permute(0, 2, 3, 1).reshape(c, -1))
+            for j in range(n):
+                p = f"stages.{i}.blocks.{j}"
+                G[p + ".fc1T"] = linT(sd[p + ".mlp.fc1.weight"])
+                G[p + ".fc2T"] = linT(sd[p + ".mlp.fc2.weight"].float() * sd[p + ".gamma"].float()[:, None])
+        self._packed[("grad", dt)] = (ver, G)
+        return G
+
+    def grad_engine(self, batch, size=None, dtype=None):
+        """Static plan of forward + backward-to-the-image (d cross_entropy / d input) for [batch,3,S,S] inputs."""
+        if size is not None and size != self.image_size:
+            raise ValueError(f"ConvNeXtVictim was built for {self.image_size}x{self.image_size} inputs, not {size}")
+        dt = dtype_code(dtype if dtype is not None else self.compute_dtype)
+        W, G = self.packed_weights(dt), self.packed_grad_weights(dt)
+        eng = self._engines.get(("grad", batch, dt))
+        if eng is None:
+            eng = _ConvNeXtGradEngine(self, W, G, batch, dt)
+            self._engines[("grad", batch, dt)] = eng
+        return eng
+
     def forward(self, x):
         B = x.shape[0]
         if x.shape[2] != self.image_size or x.shape[3] != self.image_size:
@@ -1001,6 +1037,127 @@ class ConvNeXtVictim(nn.Module):
         cur.wait_stream(eng.stream)
         out.record_stream(cur)
         return out
+
+
+class _ConvNeXtGradEngine:
+    """ConvNeXt forward with what the reverse sweep needs retained (each block's input, depthwise output and MLP pre-activation; the
+    inputs of the stem / downsampling LayerNorms), then the blocks backwards:
+        d f = d out W_fc2';  d pre = d f * gelu'(pre);  d d = LN'(d pre W_fc1; d);  d in = d out + dwconv'(d d)
+    (layer scale folded into W_fc2 as in the forward), the downsampling layers as GEMM' -> depth_to_space -> LN', the stem as
+    LN' -> GEMM' -> unpatchify, the head as Linear' -> LN' (f32) -> the average pool's broadcast."""
+
+    def __init__(self, model, W, G, batch, dt):
+        dev = next(model.parameters()).device
+        self.model, self.stream = model, torch.cuda.Stream(device=dev)
+        S, dims = model.image_size, model.dims
+        if S % 32:
+            raise ValueError("ConvNeXtVictim: image_size must be a multiple of 32 (4x stem, three 2x downsamplings)")
+        with torch.cuda.device(dev):
+            bld = Builder(dev, dt, self.stream, batch)
+            lib, plan = bld.lib, bld.plan
+            self.x = torch.zeros((batch, 3, S, S), dtype=torch.float32, device=dev)
+            self.labels = torch.zeros((batch,), dtype=torch.int64, device=dev)
+            self.grad = torch.zeros((batch, 3, S, S), dtype=torch.float32, device=dev)
+            g = S // 4
+            # ---- forward
+            patches = bld.buf((batch, g, g, 48))
+            plan.add(lib.advs_patchify, ptr(self.x), ptr(patches), batch, 3, S, S, 4, dt, keep=(self.x, patches))
+            e = bld.conv(patches, W["stem.w"], dims[0], bias=W["stem.b"], ksize=1, pad=0)
+            bld.free(patches)
+            h = bld.layernorm(e, W["stem.g"], W["stem.beta"], 1e-6)
+            side = g
+            tape = [("stem", e)]                                    # reverse sweep reads this backwards
+            for i, (n, c) in enumerate(zip(model.depths, dims)):
+                if i > 0:
+                    p = f"stages.{i}.downsample"
+                    ln = bld.layernorm(h, W[p + ".g"], W[p + ".beta"], 1e-6)
+                    s2d = bld.buf((batch, side // 2, side // 2, 4 * dims[i - 1]))
+                    plan.add(lib.advs_space_to_depth2, ptr(ln), ptr(s2d), batch, side, side, dims[i - 1], dt, keep=(ln, s2d))
+                    bld.free(ln)
+                    tape.append(("down", p, h, side, dims[i - 1], c))
+                    side //= 2
+                    h = bld.conv(s2d, W[p + ".w"], c, bias=W[p + ".b"], ksize=1, pad=0)
+                    bld.free(s2d)
+                for j in range(n):
+                    p = f"stages.{i}.blocks.{j}"
+                    d = bld.buf((batch, side, side, c))
+                    plan.add(lib.advs_dwconv2d, ptr(h), ptr(W[p + ".dw.w"]), ptr(W[p + ".dw.b"]), ptr(d), batch, side, side, c,
+                             7, 1, dt, keep=(h, d))
+                    ln = bld.layernorm(d, W[p + ".g"], W[p + ".beta"], 1e-6)
+                    pre = bld.conv(ln, W[p + ".fc1.w"], 4 * c, bias=W[p + ".fc1.b"], ksize=1, pad=0)
+                    bld.free(ln)
+                    f = bld.buf(tuple(pre.shape))
+                    plan.add(lib.advs_gelu, ptr(pre), ptr(f), pre.numel(), dt, keep=(pre, f))
+                    new = bld.conv(f, W[p + ".fc2.w"], c, bias=W[p + ".fc2.b"], residual=h, ksize=1, pad=0)
+                    bld.free(f)
+                    bld.free(h)                                     # the block input itself is not needed backwards
+                    tape.append(("block", p, d, pre, side, c))
+                    h = new
+            C = dims[-1]
+            pooled = bld.buf((batch, C), torch.float32)
+            plan.add(lib.advs_global_avgpool, ptr(h), ptr(pooled), batch, side * side, C, dt, keep=(h, pooled))
+            bld.free(h)
+            normed = bld.buf((batch, C), torch.float32)
+            plan.add(lib.advs_layernorm, ptr(pooled), ptr(W["head.g"]), ptr(W["head.beta"]), ptr(normed), batch, C,
+                     float(model.head_norm_eps), _lib.F32, keep=(pooled, normed))
+            self.logits = bld.linear(normed, W["head.w"], W["head.b"])
+            # ---- backward
+            K = self.logits.shape[1]
+            gl = bld.buf((batch, K), torch.float32)
+            plan.add(lib.advs_softmax_ce_grad, ptr(self.logits), ptr(self.labels), ptr(gl), batch, K, 1.0, keep=(self.logits, self.labels, gl))
+            gn = bld.linear(gl, G["head.wT"], None)                                  # [B, C] f32
+            gp = bld.buf((batch, C), torch.float32)
+            plan.add(lib.advs_layernorm_bwd, ptr(gn), ptr(pooled), ptr(W["head.g"]), 0, ptr(gp), batch, C, float(model.head_norm_eps),
+                     _lib.F32, keep=(gn, pooled, gp))
+            dh = bld.buf((batch, side, side, C))
+            plan.add(lib.advs_avgpool_bwd, ptr(gp), ptr(dh), batch, side * side, C, dt, keep=(gp, dh))
+
+            def ln_bwd(dy, x, gamma, rows, c):
+                dx = bld.buf(tuple(x.shape))
+                plan.add(lib.advs_layernorm_bwd, ptr(dy), ptr(x), ptr(gamma), 0, ptr(dx), rows, c, 1e-6, dt, keep=(dy, x, gamma, dx))
+                return dx
+
+            for rec in reversed(tape):
+                if rec[0] == "block":
+                    _, p, d, pre, sd, c = rec
+                    df = bld.conv(dh, G[p + ".fc2T"], 4 * c, ksize=1, pad=0)
+                    dpre = bld.buf(tuple(pre.shape))
+                    plan.add(lib.advs_gelu_bwd, ptr(pre), ptr(df), ptr(dpre), pre.numel(), dt, keep=(pre, df, dpre))
+                    bld.free(df); bld.free(pre)
+                    dln = bld.conv(dpre, G[p + ".fc1T"], c, ksize=1, pad=0)
+                    bld.free(dpre)
+                    dd = ln_bwd(dln, d, W[p + ".g"], batch * sd * sd, c)
+                    bld.free(dln); bld.free(d)
+                    din = bld.buf((batch, sd, sd, c))
+                    plan.add(lib.advs_dwconv2d_bwd, ptr(dd), ptr(W[p + ".dw.w"]), ptr(dh), ptr(din), batch, sd, sd, c, 7, dt, keep=(dd, dh, din))
+                    bld.free(dd); bld.free(dh)
+                    dh = din
+                elif rec[0] == "down":
+                    _, p, hin, sd, cin, c = rec                                   # sd: the side BEFORE the downsampling
+                    ds2d = bld.conv(dh, G[p + ".wT"], 4 * cin, ksize=1, pad=0)
+                    bld.free(dh)
+                    dln = bld.buf((batch, sd, sd, cin))
+                    plan.add(lib.advs_depth_to_space2, ptr(ds2d), ptr(dln), batch, sd, sd, cin, dt, keep=(ds2d, dln))
+                    bld.free(ds2d)
+                    dh = ln_bwd(dln, hin, W[p + ".g"], batch * sd * sd, cin)
+                    bld.free(dln); bld.free(hin)
+                else:
+                    _, e = rec
+                    de = ln_bwd(dh, e, W["stem.g"], batch * g * g, dims[0])
+                    bld.free(dh); bld.free(e)
+                    dcols = bld.conv(de, G["stemT"], 48, ksize=1, pad=0)
+                    bld.free(de)
+                    plan.add(lib.advs_unpatchify_padded, ptr(dcols), ptr(self.grad), batch, 3, S, S, 4, 48, g * g, 0, dt, keep=(dcols, self.grad))
+            self.plan, self.captured = plan, False
+            torch.cuda.synchronize(dev)
+
+    def run(self):
+        if self.model.use_graph and not self.captured:
+            self.plan.run_eager()
+            self.stream.synchronize()
+            self.plan.capture()
+            self.captured = True
+        self.plan.run()
 
 
 class _ConvNeXtEngine:

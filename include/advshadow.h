@@ -248,6 +248,15 @@ int advs_attention_bwd(const void* qkv, const void* out, const void* d_out, void
                        void* stream);
 /* dst[b * row_stride][0..c) = src[b][0..c) (f32 -> compute dtype): the classifier head's gradient enters the CLS row.          */
 int advs_scatter_row0(const float* src, void* dst, int b, long long row_stride, int c, int dtype, void* stream);
+/* ---- ConvNeXt victim backwards (timm convnext_base of ASR_fast.py:21-26; csrc/convnext_grad.hip) ------------------------------
+ * Data gradient of advs_dwconv2d (stride 1) plus the residual stream's gradient `add` (may be NULL): the forward gather with the
+ * taps mirrored; w_taps_c is the FORWARD weight layout [k*k][c] f32.                                                              */
+int advs_dwconv2d_bwd(const void* dy, const float* w_taps_c, const void* add, void* dx, int b, int h, int w, int c, int ksize,
+                      int dtype, void* stream);
+/* Inverse of advs_space_to_depth2: x [b][h/2][w/2][4c] -> y [b][h][w][c].                                                          */
+int advs_depth_to_space2(const void* x, void* y, int b, int h, int w, int c, int dtype, void* stream);
+/* Gradient of advs_global_avgpool: out[b][p][:] = g[b][:] / hw (g f32).                                                            */
+int advs_avgpool_bwd(const float* g, void* out, int b, int hw, int c, int dtype, void* stream);
 /* Gradient of advs_cls_mean_rows_f32 (the DINOv2 head input, ASR_fast.py:47-58 with a Dinov2 checkpoint): dst[b][0][:] = src[b][0..c),
  * dst[b][1..np][:] = src[b][c..2c) / np; src f32 [b][2c], dst [b][n_pad][c] in the compute dtype, other rows untouched.            */
 int advs_scatter_cls_mean(const float* src, void* dst, int b, int n_pad, int np, int c, int dtype, void* stream);

@@ -517,6 +517,37 @@ def test_dinov2_input_gradient_matches_transformers_autograd(size, prec, bound):
     assert torch.equal(again, grad)
 
 
+@pytest.mark.parametrize("prec,bound", [("fp32", 1e-3), ("bf16", 0.1), ("fp16", 0.02)])
+def test_convnext_input_gradient_matches_transformers_autograd(prec, bound):
+    """d cross_entropy / d pixel_values of the ConvNeXt victim (depthwise 7x7 gradient = the mirrored gather + the residual stream,
+    LayerNorm / GELU gradients, downsampling as GEMM' -> depth_to_space -> LN', stem as LN' -> GEMM' -> unpatchify, the pooled head)
+    against autograd over the installed transformers ConvNextForImageClassification (depths 1-1-2-1, dims 64..512, 64 px):
+    fp32 within 1e-3 of the largest component; replays bit-identical; an image's gradient does not depend on its batch."""
+    from advshadow_amd.victims import ConvNeXtVictim
+    from oracle import victims as ov
+    cfg = dict(depths=[1, 1, 2, 1], hidden_sizes=[64, 128, 256, 512], image_size=64)
+    hf = ov.hf_convnext(7, seed=5, **cfg)
+    net = ConvNeXtVictim(7, depths=cfg["depths"], dims=cfg["hidden_sizes"], image_size=64, head_norm_eps=1e-12, compute_dtype=prec)
+    net.load_state_dict(hf.state_dict())
+    net = net.to("cuda").eval()
+    x = torch.rand(3, 3, 64, 64, generator=torch.Generator().manual_seed(23))
+    labels = torch.tensor([1, 6, 3])
+    xr = x.clone().requires_grad_(True)
+    ref_logits = hf(pixel_values=xr).logits
+    F.cross_entropy(ref_logits, labels, reduction="sum").backward()
+    logits, grad = net.input_gradient(x.cuda(), labels.cuda())
+    scale = xr.grad.abs().max().item()
+    err = (grad.cpu() - xr.grad).abs().max().item()
+    print("convnext input gradient:", prec, "max", scale, "err", err)
+    assert err < bound * scale, (err, scale)
+    if prec == "fp32":
+        assert (logits.cpu() - ref_logits.detach()).abs().max().item() < 3e-4 * max(1.0, ref_logits.abs().max().item())
+    _, again = net.input_gradient(x.cuda(), labels.cuda())
+    assert torch.equal(again, grad)
+    _, one = net.input_gradient(x[1:2].cuda(), labels[1:2].cuda())
+    assert (one[0] - grad[1]).abs().max().item() < (1e-6 if prec == "fp32" else 1e-2) * scale + 1e-12
+
+
 def test_vit_victim_drives_the_gradient_attack():
     """apply_shadow(classifier=ViTVictim) (train_shadow.py:242-266 with config 4's victim): the composite stays within epsilon * mask of the
     closed-form shadow and differs from it; fp16 (config 4's dtype) agrees with fp32 in the sign of most gradient components."""
