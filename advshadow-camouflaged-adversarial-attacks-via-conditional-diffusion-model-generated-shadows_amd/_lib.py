@@ -106,6 +106,7 @@ SIGNATURES = {
     "advs_attention_bwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "advs_scatter_row0": [vp, vp, i32, C.c_longlong, i32, i32, vp],
     "advs_scatter_cls_mean": [vp, vp, i32, i32, i32, i32, i32, vp],
+    "advs_attention_bias_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "advs_dwconv2d_bwd": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "advs_depth_to_space2": [vp, vp, i32, i32, i32, i32, i32, vp],
     "advs_avgpool_bwd": [vp, vp, i32, i32, i32, i32, vp],

@@ -28,6 +28,7 @@
 struct AttnBwdP {
     const char* qkv; const char* o; const char* dO; char* dqkv;
     float* lse; float* dsum;
+    const float* bias; int bias_mod;          // optional additive score bias [bias_mod][heads][N][N] f32 in units of log2(e) (Swin)
     int B, N, n_valid, heads, d, ld, q_off, k_off, v_off, head_stride;
     float scale, scale_log2e;
 };
@@ -112,6 +113,16 @@ attn_bwd_dq_kernel(const AttnBwdP p) {
     const char* vp = base + (size_t)(p.v_off + hd * p.head_stride) * 2;
     const char* gp = p.dO + (size_t)b * p.N * crow + (size_t)hd * dbytes;
     const char* op = p.o + (size_t)b * p.N * crow + (size_t)hd * dbytes;
+    // this lane's bias row (its query), clamped so that padding lanes read something valid
+    const float* brow = p.bias ? p.bias + (((size_t)(b % p.bias_mod) * p.heads + hd) * p.N + (qi < p.N ? qi : p.N - 1)) * (size_t)p.N : nullptr;
+    auto add_bias_t = [&](f32x16& st, int key0) {                  // S'^T tile: registers = keys key0 + row(r), column = this lane's query
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int kk = key0 + 8 * a + 4 * lh;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) st[4 * a + c] += brow[kk + c < p.N ? kk + c : p.N - 1];
+        }
+    };
 
     u32x4 qf[QSTEPS], gf[QSTEPS];
     float Dn = 0.f;
@@ -148,6 +159,7 @@ attn_bwd_dq_kernel(const AttnBwdP p) {
             for (int s = 0; s < QSTEPS; ++s)
                 if (s == 0 || s < dsteps)
                     st[kb] = mma16<T>(*(const u32x4*)(sK + (kb * 32 + l31) * KS + s * 32 + lh * 16), qf[s], st[kb]);
+            if (brow) add_bias_t(st[kb], k0 + kb * 32);
         }
         if (k0 + AB_ROWS > p.n_valid) {
 #pragma unroll
@@ -199,6 +211,7 @@ attn_bwd_dq_kernel(const AttnBwdP p) {
                     st = mma16<T>(*(const u32x4*)(sK + (kb * 32 + l31) * KS + s * 32 + lh * 16), qf[s], st);
                     dp = mma16<T>(*(const u32x4*)(sV + (kb * 32 + l31) * KS + s * 32 + lh * 16), gf[s], dp);
                 }
+            if (brow) add_bias_t(st, k0 + kb * 32);
             const bool edge = k0 + kb * 32 + 32 > p.n_valid;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -260,6 +273,8 @@ attn_bwd_dkv_kernel(const AttnBwdP p) {
     const char* gp = p.dO + (size_t)b * p.N * crow + (size_t)hd * dbytes;
     const float* lsep = p.lse + ((size_t)b * p.heads + hd) * p.N;
     const float* dsp = p.dsum + ((size_t)b * p.heads + hd) * p.N;
+    // bias column of this lane's key: element (query i, key kj) at bcol[i * N]
+    const float* bcol = p.bias ? p.bias + ((size_t)(b % p.bias_mod) * p.heads + hd) * (size_t)p.N * p.N + (kj < p.N ? kj : p.N - 1) : nullptr;
 
     u32x4 kf[QSTEPS], vf[QSTEPS];
 #pragma unroll
@@ -307,6 +322,13 @@ attn_bwd_dkv_kernel(const AttnBwdP p) {
                     st = mma16<T>(*(const u32x4*)(sQ + (qb * 32 + l31) * KS + s * 32 + lh * 16), kf[s], st);
                     dp = mma16<T>(*(const u32x4*)(sG + (qb * 32 + l31) * KS + s * 32 + lh * 16), vf[s], dp);
                 }
+            if (bcol) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int qq = i0 + qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    st[r] += bcol[(size_t)(qq < p.N ? qq : p.N - 1) * p.N];
+                }
+            }
             const bool edge = i0 + qb * 32 + 32 > p.n_valid;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -360,8 +382,9 @@ static int attn_bwd_mfma_launch(const AttnBwdP& p, hipStream_t st) {
 
 // Called by advs_attention_bwd (vit_grad.hip) for 16-bit dtypes; scratch holds 2 * b * heads * n floats here.
 int attn_bwd_mfma(const void* qkv, const void* out, const void* d_out, void* d_qkv, void* scratch, int b, int n, int n_valid, int heads,
-                  int d, int ld, int q_off, int k_off, int v_off, int head_stride, int dtype, hipStream_t st) {
+                  int d, int ld, int q_off, int k_off, int v_off, int head_stride, int dtype, hipStream_t st, const float* bias, int bias_mod) {
     AttnBwdP p;
+    p.bias = bias; p.bias_mod = bias_mod > 0 ? bias_mod : 1;
     p.qkv = (const char*)qkv; p.o = (const char*)out; p.dO = (const char*)d_out; p.dqkv = (char*)d_qkv;
     p.lse = (float*)scratch; p.dsum = p.lse + (size_t)b * heads * n;
     p.B = b; p.N = n; p.n_valid = n_valid; p.heads = heads; p.d = d; p.ld = ld;

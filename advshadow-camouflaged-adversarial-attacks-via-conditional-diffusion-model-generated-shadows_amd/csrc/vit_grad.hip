@@ -136,7 +136,7 @@ template <typename T, int D>
 __global__ void __launch_bounds__(256)
 attn_bwd_q_kernel(const T* __restrict__ qkv, const T* __restrict__ o, const T* __restrict__ dO, T* __restrict__ dqkv,
                   float* __restrict__ sP, float* __restrict__ sdS, int n, int n_valid, int heads, int d, int ld, int q_off, int k_off,
-                  int v_off, int head_stride, float scale) {
+                  int v_off, int head_stride, float scale, const float* __restrict__ bias, int bias_mod) {
     extern __shared__ __attribute__((aligned(16))) float lds[];       // K [n_valid][D], V [n_valid][D], zero beyond d
     float* sK = lds;
     float* sV = lds + (size_t)n_valid * D;
@@ -170,9 +170,11 @@ attn_bwd_q_kernel(const T* __restrict__ qkv, const T* __restrict__ o, const T* _
             if (c < d) Dn = fmaf(g[c], Elt<T>::ld(op + c), Dn);
             acc[c] = 0.f;
         }
+        // additive score bias (Swin), given in units of log2(e): row i of block b % bias_mod
+        const float* brow = bias ? bias + (((size_t)(b % bias_mod) * heads + hd) * n + i) * (size_t)n : nullptr;
         float mx = -INFINITY, l = 0.f;
         for (int j = 0; j < n_valid; ++j) {
-            float s = 0.f;
+            float s = brow ? brow[j] * 0.6931471805599453f : 0.f;
 #pragma unroll
             for (int c = 0; c < D; ++c) s = fmaf(q[c], sK[j * D + c], s);
             const float m2 = fmaxf(mx, s);
@@ -181,7 +183,7 @@ attn_bwd_q_kernel(const T* __restrict__ qkv, const T* __restrict__ o, const T* _
         }
         const float inv = 1.0f / l;
         for (int j = 0; j < n_valid; ++j) {
-            float s = 0.f, dp = 0.f;
+            float s = brow ? brow[j] * 0.6931471805599453f : 0.f, dp = 0.f;
 #pragma unroll
             for (int c = 0; c < D; ++c) { s = fmaf(q[c], sK[j * D + c], s); dp = fmaf(g[c], sV[j * D + c], dp); }
             const float p = expf(s - mx) * inv;
@@ -236,7 +238,8 @@ extern "C" size_t advs_attention_bwd_scratch_bytes(int b, int n, int heads) { re
 
 template <typename T, int D>
 static int attn_bwd_launch(const void* qkv, const void* out, const void* d_out, void* d_qkv, float* sP, float* sdS, int b, int n,
-                           int n_valid, int heads, int d, int ld, int q_off, int k_off, int v_off, int head_stride, hipStream_t st) {
+                           int n_valid, int heads, int d, int ld, int q_off, int k_off, int v_off, int head_stride, hipStream_t st,
+                           const float* bias, int bias_mod) {
     const size_t lds = (size_t)2 * n_valid * D * sizeof(float);
     ADVS_REQUIRE(lds <= 160 * 1024, "attention_bwd: %d keys x d %d do not fit the LDS (this path is for short sequences)", n_valid, d);
     static bool attr_set = false;
@@ -248,7 +251,7 @@ static int attn_bwd_launch(const void* qkv, const void* out, const void* d_out, 
     const float scale = (float)(1.0 / sqrt((double)d));
     const dim3 grid(cdiv(n, 256), heads, b);
     attn_bwd_q_kernel<T, D><<<grid, 256, lds, st>>>((const T*)qkv, (const T*)out, (const T*)d_out, (T*)d_qkv, sP, sdS, n, n_valid, heads, d,
-                                                    ld, q_off, k_off, v_off, head_stride, scale);
+                                                    ld, q_off, k_off, v_off, head_stride, scale, bias, bias_mod > 0 ? bias_mod : 1);
     ADVS_CHECK_LAUNCH("attention_bwd (queries)");
     attn_bwd_kv_kernel<T, D><<<grid, 256, lds, st>>>((const T*)qkv, (const T*)d_out, (T*)d_qkv, sP, sdS, n, n_valid, heads, d, ld, q_off,
                                                      k_off, v_off, head_stride, scale);
@@ -257,11 +260,28 @@ static int attn_bwd_launch(const void* qkv, const void* out, const void* d_out, 
 }
 // 16-bit dtypes: the MFMA kernels of attention_bwd.hip
 int attn_bwd_mfma(const void* qkv, const void* out, const void* d_out, void* d_qkv, void* scratch, int b, int n, int n_valid, int heads,
-                  int d, int ld, int q_off, int k_off, int v_off, int head_stride, int dtype, hipStream_t st);
+                  int d, int ld, int q_off, int k_off, int v_off, int head_stride, int dtype, hipStream_t st, const float* bias, int bias_mod);
+static int attention_bwd_impl(const void* qkv, const void* out, const void* d_out, void* d_qkv, void* scratch, int b, int n, int n_valid,
+                              int heads, int d, int ld, int q_off, int k_off, int v_off, int head_stride, int dtype, void* stream,
+                              const float* bias, int bias_mod);
 
 extern "C" int advs_attention_bwd(const void* qkv, const void* out, const void* d_out, void* d_qkv, void* scratch, int b, int n,
                                   int n_valid, int heads, int d, int ld, int q_off, int k_off, int v_off, int head_stride, int dtype,
                                   void* stream) {
+    return attention_bwd_impl(qkv, out, d_out, d_qkv, scratch, b, n, n_valid, heads, d, ld, q_off, k_off, v_off, head_stride, dtype, stream,
+                              nullptr, 1);
+}
+// Gradient of advs_attention_bias (Swin's windows: relative position bias + shifted-window mask inside the softmax).
+extern "C" int advs_attention_bias_bwd(const void* qkv, const void* out, const void* d_out, void* d_qkv, void* scratch,
+                                       const float* bias_log2e, int bias_mod, int b, int n, int heads, int d, int ld, int q_off, int k_off,
+                                       int v_off, int head_stride, int dtype, void* stream) {
+    ADVS_REQUIRE(bias_log2e && bias_mod > 0, "attention_bias_bwd: bias is required");
+    return attention_bwd_impl(qkv, out, d_out, d_qkv, scratch, b, n, n, heads, d, ld, q_off, k_off, v_off, head_stride, dtype, stream,
+                              bias_log2e, bias_mod);
+}
+static int attention_bwd_impl(const void* qkv, const void* out, const void* d_out, void* d_qkv, void* scratch, int b, int n, int n_valid,
+                              int heads, int d, int ld, int q_off, int k_off, int v_off, int head_stride, int dtype, void* stream,
+                              const float* bias, int bias_mod) {
     ADVS_REQUIRE(dtype_ok(dtype), "advs_attention_bwd: unknown dtype code %d", dtype);
     ADVS_REQUIRE(qkv && out && d_out && d_qkv && scratch && b > 0 && n > 0 && n_valid > 0 && n_valid <= n && heads > 0, "attention_bwd: bad args");
     ADVS_REQUIRE(d > 0 && d <= 64, "attention_bwd: d=%d must be in 1..64", d);
@@ -269,11 +289,11 @@ extern "C" int advs_attention_bwd(const void* qkv, const void* out, const void* 
     if (dtype != ADVS_F32 && !valu_only && d % 8 == 0 && ld % 8 == 0 && q_off % 8 == 0 && k_off % 8 == 0 && v_off % 8 == 0 &&
         head_stride % 8 == 0)
         return attn_bwd_mfma(qkv, out, d_out, d_qkv, scratch, b, n, n_valid, heads, d, ld, q_off, k_off, v_off, head_stride, dtype,
-                             (hipStream_t)stream);
+                             (hipStream_t)stream, bias, bias_mod);
     float* sP = (float*)scratch;
     float* sdS = sP + (size_t)b * heads * n * n;
-    if (d <= 32) ADVS_SWITCH_T(dtype, return (attn_bwd_launch<T, 32>(qkv, out, d_out, d_qkv, sP, sdS, b, n, n_valid, heads, d, ld, q_off, k_off, v_off, head_stride, (hipStream_t)stream)));
-    ADVS_SWITCH_T(dtype, return (attn_bwd_launch<T, 64>(qkv, out, d_out, d_qkv, sP, sdS, b, n, n_valid, heads, d, ld, q_off, k_off, v_off, head_stride, (hipStream_t)stream)));
+    if (d <= 32) ADVS_SWITCH_T(dtype, return (attn_bwd_launch<T, 32>(qkv, out, d_out, d_qkv, sP, sdS, b, n, n_valid, heads, d, ld, q_off, k_off, v_off, head_stride, (hipStream_t)stream, bias, bias_mod)));
+    ADVS_SWITCH_T(dtype, return (attn_bwd_launch<T, 64>(qkv, out, d_out, d_qkv, sP, sdS, b, n, n_valid, heads, d, ld, q_off, k_off, v_off, head_stride, (hipStream_t)stream, bias, bias_mod)));
     return ADVS_ERR_ARG;                    // not reached
 }
 

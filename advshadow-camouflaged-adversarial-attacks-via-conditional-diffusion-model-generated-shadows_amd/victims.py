@@ -1263,7 +1263,7 @@ def swin_canonical_state_dict(sd, depths):
     return out
 
 
-class SwinVictim(nn.Module):
+class SwinVictim(_InputGradient, nn.Module):
     """``timm.create_model('swin_base_patch4_window7_224', num_classes=37)`` (ASR_fast.py:27-32) on the HIP kernels.
     Per block: LayerNorm -> cyclic shift + window partition (one gather) -> qkv GEMM -> window attention with the
     relative position bias and the shifted-window mask as an additive score bias -> projection GEMM -> inverse gather
@@ -1390,6 +1390,45 @@ class SwinVictim(nn.Module):
             self._engines[(batch, dt)] = eng
         return eng
 
+    # ---- backward to the image (the gradient attack of tools/train_shadow.py:177-221 with this victim) ------------------
+    def packed_grad_weights(self, dt):
+        """Every Linear's weight transposed (its data gradient is a GEMM against W); patch merging in the gather's channel order."""
+        ver = self._version()
+        hit = self._packed.get(("grad", dt))
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        self.packed_weights(dt)
+        dev = next(self.parameters()).device
+        sd = {k: v.detach() for k, v in self.state_dict().items()}
+        linT = lambda w: pack_conv_weight(w.float().t().contiguous().reshape(w.shape[1], w.shape[0], 1, 1), dt)
+        G = {"peT": linT(sd["patch_embed.proj.weight"].float().reshape(self.embed_dim, -1)),
+             "head.wT": sd["head.fc.weight"].float().t().contiguous()}
+        for i, nb in enumerate(self.depths):
+            c = self.embed_dim << i
+            if i > 0:
+                p = f"layers.{i}.downsample"
+                cp = c // 2
+                perm = torch.cat([torch.arange(cp) + blk * cp for blk in (0, 2, 1, 3)]).to(dev)
+                G[p + ".wT"] = linT(sd[p + ".reduction.weight"].float()[:, perm])
+            for j in range(nb):
+                p = f"layers.{i}.blocks.{j}"
+                for src, dst in ((".attn.qkv", ".qkvT"), (".attn.proj", ".projT"), (".mlp.fc1", ".fc1T"), (".mlp.fc2", ".fc2T")):
+                    G[p + dst] = linT(sd[p + src + ".weight"])
+        self._packed[("grad", dt)] = (ver, G)
+        return G
+
+    def grad_engine(self, batch, size=None, dtype=None):
+        """Static plan of forward + backward-to-the-image (d cross_entropy / d input) for [batch,3,S,S] inputs."""
+        if size is not None and size != self.image_size:
+            raise ValueError(f"SwinVictim was built for {self.image_size}x{self.image_size} inputs, not {size}")
+        dt = dtype_code(dtype if dtype is not None else self.compute_dtype)
+        W, G = self.packed_weights(dt), self.packed_grad_weights(dt)
+        eng = self._engines.get(("grad", batch, dt))
+        if eng is None:
+            eng = _SwinGradEngine(self, W, G, batch, dt)
+            self._engines[("grad", batch, dt)] = eng
+        return eng
+
     def forward(self, x):
         if x.shape[2] != self.image_size or x.shape[3] != self.image_size:
             raise ValueError(f"SwinVictim was built for {self.image_size}x{self.image_size} inputs, got {tuple(x.shape[2:])}")
@@ -1403,6 +1442,152 @@ class SwinVictim(nn.Module):
         cur.wait_stream(eng.stream)
         out.record_stream(cur)
         return out
+
+
+class _SwinGradEngine:
+    """Swin forward with what the reverse sweep needs retained (each block's input, qkv, attention output, the stream after the
+    attention branch and the MLP pre-activation; the gathered input of every patch-merging LayerNorm), then the blocks backwards:
+        d f = d out W_fc2';  d pre = d f * gelu'(pre);  d a = d out + LN2'(d pre W_fc1'; a)
+        d pr = partition(shift(d a));  d qkv = attention'(d pr W_proj'; qkv, att, bias);  d in = d a + LN1'(unshift(merge(d qkv W_qkv')); in)
+    -- the gradient of the inverse window gather is the forward gather and vice versa (both are permutations)."""
+
+    def __init__(self, model, W, G, batch, dt):
+        dev = next(model.parameters()).device
+        self.model, self.stream = model, torch.cuda.Stream(device=dev)
+        S, ps = model.image_size, model.patch_size
+        geo = model._stage_geometry()
+        for res, win, _ in geo:
+            if res % win:
+                raise ValueError(f"SwinVictim: a {res}x{res} map is not a whole number of {win}-pixel windows")
+        with torch.cuda.device(dev):
+            bld = Builder(dev, dt, self.stream, batch)
+            lib, plan = bld.lib, bld.plan
+            self.x = torch.zeros((batch, 3, S, S), dtype=torch.float32, device=dev)
+            self.labels = torch.zeros((batch,), dtype=torch.int64, device=dev)
+            self.grad = torch.zeros((batch, 3, S, S), dtype=torch.float32, device=dev)
+            g = S // ps
+            kcols = 3 * ps * ps
+            # ---- forward
+            patches = bld.buf((batch, g, g, kcols))
+            plan.add(lib.advs_patchify, ptr(self.x), ptr(patches), batch, 3, S, S, ps, dt, keep=(self.x, patches))
+            e = bld.conv(patches, W["pe.w"], model.embed_dim, bias=W["pe.b"], ksize=1, pad=0)
+            bld.free(patches)
+            h = bld.layernorm(e, W["pe.g"], W["pe.beta"], 1e-5)
+            tape = [("pe", e)]
+            max_scratch = 0
+            for i, nb in enumerate(model.depths):
+                c = model.embed_dim << i
+                res, win, shift = geo[i]
+                heads = model.num_heads[i]
+                d = c // heads
+                if i > 0:
+                    p = f"layers.{i}.downsample"
+                    s2d = bld.buf((batch, res, res, 2 * c))
+                    plan.add(lib.advs_space_to_depth2, ptr(h), ptr(s2d), batch, 2 * res, 2 * res, c // 2, dt, keep=(h, s2d))
+                    bld.free(h)
+                    ln = bld.layernorm(s2d, W[p + ".g"], W[p + ".beta"], 1e-5)
+                    h = bld.conv(ln, W[p + ".w"], c, ksize=1, pad=0)
+                    bld.free(ln)
+                    tape.append(("down", p, s2d, res, c))
+                nW = (res // win) ** 2
+                max_scratch = max(max_scratch, lib.advs_attention_bwd_scratch_bytes(batch * nW, win * win, heads))
+                for j in range(nb):
+                    p = f"layers.{i}.blocks.{j}"
+                    sh = shift if j % 2 else 0
+                    ln = bld.layernorm(h, W[p + ".norm1.g"], W[p + ".norm1.beta"], 1e-5)
+                    wins = bld.window_shift(ln, win, sh)
+                    bld.free(ln)
+                    qkv = bld.conv(wins, W[p + ".qkv.w"], 3 * c, bias=W[p + ".qkv.b"], ksize=1, pad=0)
+                    bld.free(wins)
+                    att = bld.attention_bias(qkv, heads, d, 0, c, 2 * c, d, W[p + ".bias"], nW if sh else 1)
+                    pr = bld.conv(att, W[p + ".proj.w"], c, bias=W[p + ".proj.b"], ksize=1, pad=0)
+                    a = bld.window_shift(pr, win, sh, inverse=True, residual=h, image_hw=(res, res))
+                    bld.free(pr)
+                    ln = bld.layernorm(a, W[p + ".norm2.g"], W[p + ".norm2.beta"], 1e-5)
+                    pre = bld.conv(ln, W[p + ".fc1.w"], W[p + ".fc1.b"].numel(), bias=W[p + ".fc1.b"], ksize=1, pad=0)
+                    bld.free(ln)
+                    f = bld.buf(tuple(pre.shape))
+                    plan.add(lib.advs_gelu, ptr(pre), ptr(f), pre.numel(), dt, keep=(pre, f))
+                    out = bld.conv(f, W[p + ".fc2.w"], c, bias=W[p + ".fc2.b"], residual=a, ksize=1, pad=0)
+                    bld.free(f)
+                    tape.append(("block", p, h, qkv, att, a, pre, res, win, sh, c, heads, d, nW))
+                    h = out
+            cl = model.embed_dim << (len(model.depths) - 1)
+            rl = geo[-1][0]
+            ln = bld.layernorm(h, W["norm.g"], W["norm.beta"], 1e-5)
+            pooled = bld.buf((batch, cl), torch.float32)
+            plan.add(lib.advs_global_avgpool, ptr(ln), ptr(pooled), batch, rl * rl, cl, dt, keep=(ln, pooled))
+            bld.free(ln)
+            self.logits = bld.linear(pooled, W["head.w"], W["head.b"])
+            # ---- backward
+            K = self.logits.shape[1]
+            gl = bld.buf((batch, K), torch.float32)
+            plan.add(lib.advs_softmax_ce_grad, ptr(self.logits), ptr(self.labels), ptr(gl), batch, K, 1.0, keep=(self.logits, self.labels, gl))
+            gp = bld.linear(gl, G["head.wT"], None)                                  # [B, cl] f32
+            dln = bld.buf((batch, rl, rl, cl))
+            plan.add(lib.advs_avgpool_bwd, ptr(gp), ptr(dln), batch, rl * rl, cl, dt, keep=(gp, dln))
+            scratch = torch.empty(max_scratch, dtype=torch.uint8, device=dev)
+
+            def ln_bwd(dy, x, gamma, add):
+                dx = bld.buf(tuple(x.shape))
+                rows = x.numel() // x.shape[-1]
+                plan.add(lib.advs_layernorm_bwd, ptr(dy), ptr(x), ptr(gamma), ptr(add), ptr(dx), rows, x.shape[-1], 1e-5, dt,
+                         keep=(dy, x, gamma, add, dx))
+                return dx
+
+            dh = ln_bwd(dln, h, W["norm.g"], None)
+            bld.free(dln); bld.free(h)
+            for rec in reversed(tape):
+                if rec[0] == "block":
+                    _, p, hin, qkv, att, a, pre, res, win, sh, c, heads, d, nW = rec
+                    df = bld.conv(dh, G[p + ".fc2T"], pre.shape[-1], ksize=1, pad=0)
+                    dpre = bld.buf(tuple(pre.shape))
+                    plan.add(lib.advs_gelu_bwd, ptr(pre), ptr(df), ptr(dpre), pre.numel(), dt, keep=(pre, df, dpre))
+                    bld.free(df); bld.free(pre)
+                    dl2 = bld.conv(dpre, G[p + ".fc1T"], c, ksize=1, pad=0)
+                    bld.free(dpre)
+                    da = ln_bwd(dl2, a, W[p + ".norm2.g"], dh)
+                    bld.free(dl2); bld.free(dh); bld.free(a)
+                    dpr = bld.window_shift(da, win, sh)                               # gradient of the inverse gather = the gather
+                    datt = bld.conv(dpr, G[p + ".projT"], c, ksize=1, pad=0)
+                    bld.free(dpr)
+                    dqkv = bld.buf(tuple(qkv.shape))
+                    plan.add(lib.advs_attention_bias_bwd, ptr(qkv), ptr(att), ptr(datt), ptr(dqkv), ptr(scratch), ptr(W[p + ".bias"]),
+                             nW if sh else 1, batch * nW, win * win, heads, d, 3 * c, 0, c, 2 * c, d, dt,
+                             keep=(qkv, att, datt, dqkv, scratch, W[p + ".bias"]))
+                    bld.free(datt); bld.free(qkv); bld.free(att)
+                    dwins = bld.conv(dqkv, G[p + ".qkvT"], c, ksize=1, pad=0)
+                    bld.free(dqkv)
+                    dl1 = bld.window_shift(dwins, win, sh, inverse=True, residual=None, image_hw=(res, res))
+                    bld.free(dwins)
+                    dh = ln_bwd(dl1, hin, W[p + ".norm1.g"], da)
+                    bld.free(dl1); bld.free(da); bld.free(hin)
+                elif rec[0] == "down":
+                    _, p, s2d, res, c = rec
+                    dlo = bld.conv(dh, G[p + ".wT"], 2 * c, ksize=1, pad=0)
+                    bld.free(dh)
+                    ds2d = ln_bwd(dlo, s2d, W[p + ".g"], None)
+                    bld.free(dlo); bld.free(s2d)
+                    dh = bld.buf((batch, 2 * res, 2 * res, c // 2))
+                    plan.add(lib.advs_depth_to_space2, ptr(ds2d), ptr(dh), batch, 2 * res, 2 * res, c // 2, dt, keep=(ds2d, dh))
+                    bld.free(ds2d)
+                else:
+                    _, e = rec
+                    de = ln_bwd(dh, e, W["pe.g"], None)
+                    bld.free(dh); bld.free(e)
+                    dcols = bld.conv(de, G["peT"], kcols, ksize=1, pad=0)
+                    bld.free(de)
+                    plan.add(lib.advs_unpatchify_padded, ptr(dcols), ptr(self.grad), batch, 3, S, S, ps, kcols, g * g, 0, dt, keep=(dcols, self.grad))
+            self.plan, self.captured = plan, False
+            torch.cuda.synchronize(dev)
+
+    def run(self):
+        if self.model.use_graph and not self.captured:
+            self.plan.run_eager()
+            self.stream.synchronize()
+            self.plan.capture()
+            self.captured = True
+        self.plan.run()
 
 
 class _SwinEngine:

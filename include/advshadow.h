@@ -246,6 +246,11 @@ size_t advs_attention_bwd_scratch_bytes(int b, int n, int heads);
 int advs_attention_bwd(const void* qkv, const void* out, const void* d_out, void* d_qkv, void* scratch, int b, int n,
                        int n_valid, int heads, int d, int ld, int q_off, int k_off, int v_off, int head_stride, int dtype,
                        void* stream);
+/* Gradient of advs_attention_bias (Swin's windows, swin_transformer.py WindowAttention.forward): as advs_attention_bwd with the same
+ * additive score bias (units of log2 e, block i % bias_mod for sequence i) inside the recomputed softmax; every token is a key.    */
+int advs_attention_bias_bwd(const void* qkv, const void* out, const void* d_out, void* d_qkv, void* scratch, const float* bias_log2e,
+                            int bias_mod, int b, int n, int heads, int d, int ld, int q_off, int k_off, int v_off, int head_stride,
+                            int dtype, void* stream);
 /* dst[b * row_stride][0..c) = src[b][0..c) (f32 -> compute dtype): the classifier head's gradient enters the CLS row.          */
 int advs_scatter_row0(const float* src, void* dst, int b, long long row_stride, int c, int dtype, void* stream);
 /* ---- ConvNeXt victim backwards (timm convnext_base of ASR_fast.py:21-26; csrc/convnext_grad.hip) ------------------------------

@@ -548,6 +548,35 @@ def test_convnext_input_gradient_matches_transformers_autograd(prec, bound):
     assert (one[0] - grad[1]).abs().max().item() < (1e-6 if prec == "fp32" else 1e-2) * scale + 1e-12
 
 
+@pytest.mark.parametrize("prec,bound", [("fp32", 1e-3), ("bf16", 0.1), ("fp16", 0.02)])
+def test_swin_input_gradient_matches_transformers_autograd(prec, bound):
+    """d cross_entropy / d pixel_values of the Swin victim (window attention gradient with the relative position bias and the
+    shifted-window mask inside the recomputed softmax, the window gathers run as each other's gradients, patch merging as
+    GEMM' -> LN' -> depth_to_space) against autograd over the installed transformers SwinForImageClassification (embed 32, depths
+    2-2, heads 2-4, window 4, 64 px: shifted windows in stage 1, whole-map windows in stage 2); replays bit-identical."""
+    from advshadow_amd.victims import SwinVictim
+    from oracle import victims as ov
+    cfg = dict(image_size=64, patch_size=4, embed_dim=32, depths=[2, 2], num_heads=[2, 4], window_size=4)
+    hf = ov.hf_swin(7, seed=7, **cfg)
+    net = SwinVictim(7, embed_dim=32, depths=[2, 2], num_heads=[2, 4], window_size=4, image_size=64, compute_dtype=prec)
+    net.load_state_dict(hf.state_dict())
+    net = net.to("cuda").eval()
+    x = torch.rand(3, 3, 64, 64, generator=torch.Generator().manual_seed(25))
+    labels = torch.tensor([2, 0, 5])
+    xr = x.clone().requires_grad_(True)
+    ref_logits = hf(pixel_values=xr).logits
+    F.cross_entropy(ref_logits, labels, reduction="sum").backward()
+    logits, grad = net.input_gradient(x.cuda(), labels.cuda())
+    scale = xr.grad.abs().max().item()
+    err = (grad.cpu() - xr.grad).abs().max().item()
+    print("swin input gradient:", prec, "max", scale, "err", err)
+    assert err < bound * scale, (err, scale)
+    if prec == "fp32":
+        assert (logits.cpu() - ref_logits.detach()).abs().max().item() < 3e-4 * max(1.0, ref_logits.abs().max().item())
+    _, again = net.input_gradient(x.cuda(), labels.cuda())
+    assert torch.equal(again, grad)
+
+
 def test_vit_victim_drives_the_gradient_attack():
     """apply_shadow(classifier=ViTVictim) (train_shadow.py:242-266 with config 4's victim): the composite stays within epsilon * mask of the
     closed-form shadow and differs from it; fp16 (config 4's dtype) agrees with fp32 in the sign of most gradient components."""
