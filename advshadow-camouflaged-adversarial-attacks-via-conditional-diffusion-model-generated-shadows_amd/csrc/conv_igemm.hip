@@ -324,6 +324,8 @@ static int conv_dispatch(ConvKP& p, int tile, hipStream_t st) {
     if (tile == 0) tile = pick_tile((long long)p.Ho * p.Wo, p.Cout);
     if (p.mask) {                       // ReLU-backward epilogue: its own instantiations, the others never read p.mask
         if (tile == 4) return conv_launch<T, 256, 256, 128, 64, 2, true, true>(p, st);
+        if (tile == 15) return conv_launch<T, 64, 128, 32, 64, 2, false, true>(p, st);
+        if (tile == 16) return conv_launch<T, 64, 64, 32, 32, 2, false, true>(p, st);
         return conv_launch<T, 128, 128, 64, 64, 2, false, true>(p, st);
     }
     switch (tile) {
@@ -339,6 +341,9 @@ static int conv_dispatch(ConvKP& p, int tile, hipStream_t st) {
         case 5: return conv_launch<T, 256, 128, 64, 64, 3>(p, st);
         case 6: return conv_launch<T, 128, 128, 64, 64, 3>(p, st);
         case 7: return conv_launch<T, 256, 128, 128, 64, 3>(p, st);
+        // small maps (the victims' 28x28 .. 7x7 layers): 64-row tiles, so that a launch still has a workgroup for every CU
+        case 15: return conv_launch<T, 64, 128, 32, 64, 2, false>(p, st);
+        case 16: return conv_launch<T, 64, 64, 32, 32, 2, false>(p, st);
         default: ADVS_FAIL(ADVS_ERR_ARG, "conv2d: unknown tile id %d", tile);
     }
 }
@@ -353,6 +358,14 @@ static int pick_tile(long long m_img, int cout) {
     // The rule looks at ONE image's pixels (m_img = Ho*Wo), never at the batch: the tile fixes the order of the
     // K summation, so an image must get the same tile whichever batch it is evaluated in (batch-shard equality).
     const long long blocks256 = (long long)cdiv(m_img, 256) * cdiv(cout, 256);
+    // Small maps (the victims' 56x56 .. 7x7 layers, the ViTs' token rows): 64-row tiles in 4-wave workgroups -- three to a CU, and a
+    // launch of a few thousand rows still has work for every CU.  ResNet-50 attack at batch 32: 396 -> 490 images/s, ViT-B 229 -> 233,
+    // VGG16 and the eps-predictor unchanged (tools/_diag sweep, round 2).  64 x 64 tiles below 15 x 15 pixels only: ViT's wide GEMMs
+    // (208 rows per image, 768-3072 columns) lose 9 % on them.  The environment variables are tuning knobs.
+    static const long long t15_m = getenv("ADVS_T15_M") ? atoll(getenv("ADVS_T15_M")) : 3136;
+    static const long long t16_m = getenv("ADVS_T16_M") ? atoll(getenv("ADVS_T16_M")) : 196;
+    if (m_img <= t16_m) return 16;
+    if (m_img <= t15_m) return 15;
     return (cout % 256 == 0 && blocks256 >= 12) ? 4 : 1;
 }
 // the 16x16-pixel halo kernel wins wherever it applies (3x3, stride 1, no upsample / extra operand, image a
@@ -382,7 +395,7 @@ extern "C" int advs_conv_resolve_tile(const advs_conv_args* a) {
     return resolve_tile(a, ho * wo);
 }
 extern "C" int advs_conv_tile_rows(int tile) {
-    switch (tile) { case 1: case 2: case 5: case 6: case 8: case 10: case 12: case 13: return 64; case 3: case 4: case 7: case 9: case 14: return 128; default: return 0; }
+    switch (tile) { case 1: case 2: case 5: case 6: case 8: case 10: case 12: case 13: return 64; case 3: case 4: case 7: case 9: case 14: return 128; case 15: case 16: return 32; default: return 0; }
 }
 
 extern "C" int advs_conv2d(const advs_conv_args* a, void* stream) {
@@ -407,8 +420,8 @@ extern "C" int advs_conv2d(const advs_conv_args* a, void* stream) {
     p.stats = a->stats;
     p.fast_epi = 0;
     p.mask = (const char*)a->relu_mask;
-    ADVS_REQUIRE(!a->relu_mask || (!a->stats && a->upsample != ADVS_UPSAMPLE_SUBPIXEL && (a->tile == 0 || a->tile == 1 || a->tile == 4)),
-                 "conv2d: relu_mask needs a per-tap tile (0, 1 or 4), no stats, no sub-pixel upsample");
+    ADVS_REQUIRE(!a->relu_mask || (!a->stats && a->upsample != ADVS_UPSAMPLE_SUBPIXEL && (a->tile == 0 || a->tile == 1 || a->tile == 4 || a->tile == 15 || a->tile == 16)),
+                 "conv2d: relu_mask needs a per-tap tile (0, 1, 4, 15 or 16), no stats, no sub-pixel upsample");
     p.B = a->b; p.H = a->h; p.W = a->w_; p.C1 = a->c1; p.C2 = a->c2; p.Cout = a->cout;
     p.LD1 = a->ld1 > 0 ? a->ld1 : a->c1; p.LD2 = a->ld2 > 0 ? a->ld2 : a->c2;
     ADVS_REQUIRE(p.LD1 <= a->c1 && p.LD2 <= a->c2 && (p.LD1 * esz) % 16 == 0 && (p.LD2 * esz) % 16 == 0 && a->ld1 >= 0 && a->ld2 >= 0,

@@ -75,7 +75,8 @@ typedef struct advs_conv_args {
     int tile;                           /* 0 = choose; 1: 128x128, 2|3: 256x128, 4: 256x256,
                                            10: 16x16-pixel halo tile (3x3 stride 1 only); 12 (implied by
                                            ADVS_UPSAMPLE_SUBPIXEL): its 4-tap sub-pixel form; 14: 16x32-pixel
-                                           halo tile, one wave per SIMD (16-bit, experimental, never chosen)  */
+                                           halo tile, one wave per SIMD (16-bit, experimental, never chosen);
+                                           15: 64x128, 16: 64x64 (chosen for maps of <= 56x56 / 14x14 pixels)  */
     float* stats;                       /* NULL, or [ceil(M/rows)][cout][2]: per row block (rows =
                                            advs_conv_tile_rows(tile), must divide ho*wo) and channel the
                                            (sum, sum of squares) of y as stored -> advs_groupnorm_stats */

@@ -46,7 +46,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 14])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 14, 15, 16])
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv2d(case, dt, tile):
