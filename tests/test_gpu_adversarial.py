@@ -490,6 +490,44 @@ def test_vit_input_gradient_matches_transformers_autograd(cfg, batch):
     assert (one[0] - grad[1]).abs().max().item() < 1e-6 * scale + 1e-12
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("Bs,H,d,n,mod", [(8, 4, 32, 49, 4), (6, 2, 16, 16, 1), (4, 3, 64, 144, 2)])
+def test_attention_bias_backward_matches_autograd(prec, Bs, H, d, n, mod):
+    """Gradient of softmax(q k^T / sqrt d + bias) v with Swin's additive bias (relative position + -100 masks, block i % mod for
+    sequence i; 49-token windows of swin_base, 16-token windows of the small test config, a 144-token case spanning three key
+    stages) against fp32 autograd over the same rounded inputs: the f32 VALU path to 2e-5, the MFMA path to 2 % (bf16) / 0.4 % (fp16)."""
+    import math
+    lib = OneOp(prec, 1).b.lib
+    td = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[prec]
+    code = {"fp32": 0, "bf16": 1, "fp16": 2}[prec]
+    s = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(31 + n)
+    C = H * d
+    qkv16 = torch.randn(Bs, n, 3 * C, generator=g).to(td)
+    bias = torch.randn(mod, H, n, n, generator=g)
+    bias[:, :, : n // 3, n // 2:] -= 100.0 * (torch.rand(mod, 1, n // 3, n - n // 2, generator=g) > 0.5)      # masked pairs
+    qkv = qkv16.float().requires_grad_(True)
+    q, k, v = (qkv[:, :, i * C:(i + 1) * C].reshape(Bs, n, H, d).transpose(1, 2) for i in range(3))
+    sc = (q @ k.transpose(-1, -2)) / math.sqrt(d) + bias[torch.arange(Bs) % mod]
+    o = (torch.softmax(sc, -1) @ v).transpose(1, 2).reshape(Bs, n, C)
+    do16 = torch.randn(Bs, n, C, generator=g).to(td)
+    o.backward(do16.float())
+    qd, od, dod = qkv16.to(dev()), o.detach().to(td).to(dev()).contiguous(), do16.to(dev())
+    bl2 = (bias * 1.4426950408889634).contiguous().to(dev())
+    scratch = torch.empty(lib.advs_attention_bwd_scratch_bytes(Bs, n, H), dtype=torch.uint8, device=dev())
+    dq = torch.full_like(qd, 7.0)
+    assert lib.advs_attention_bias_bwd(ptr(qd), ptr(od), ptr(dod), ptr(dq), ptr(scratch), ptr(bl2), mod, Bs, n, H, d, 3 * C, 0, C, 2 * C, d,
+                                       code, s) == 0
+    torch.cuda.synchronize()
+    got, ref = dq.float().cpu(), qkv.grad
+    assert torch.isfinite(got).all()
+    tol = {"fp32": 2e-5, "bf16": 2e-2, "fp16": 4e-3}[prec]
+    for i, name in enumerate("qkv"):
+        r, o_ = ref[:, :, i * C:(i + 1) * C], got[:, :, i * C:(i + 1) * C]
+        err, scale = (o_ - r).abs().max().item(), r.abs().max().item()
+        assert err < tol * max(scale, 1.0), (name, err, scale)
+
+
 @pytest.mark.parametrize("size,prec,bound", [(56, "fp32", 1e-3), (112, "fp32", 1e-3), (56, "bf16", 0.08), (56, "fp16", 0.02)])
 def test_dinov2_input_gradient_matches_transformers_autograd(size, prec, bound):
     """d cross_entropy / d pixel_values of the DINOv2 victim (LayerScale folded into the transposed weights, the [cls | mean] head
