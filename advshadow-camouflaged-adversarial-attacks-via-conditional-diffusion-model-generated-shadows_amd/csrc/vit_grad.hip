@@ -47,10 +47,97 @@ layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const fl
         }
     }
 }
+// 16-bit storage, C a multiple of 8 and <= 2048: the row lives in registers (one pass over x and dy, 16-byte accesses).  LPR lanes
+// (a power of two >= C / 8 vectors, at most 64) share a row, NV vectors each; 64 / LPR rows per wave.  Same arithmetic as above
+// (mean, then the centred second moment, then the two gradient means), so the result is the same up to summation order.
+template <typename T, int NV>
+__global__ void __launch_bounds__(256)
+layernorm_bwd16_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma, const T* __restrict__ add,
+                       T* __restrict__ dx, long long rows, int C, float eps, int LPR) {
+    const int lane = threadIdx.x & 63, sub = lane & (LPR - 1), rpw = 64 / LPR;
+    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    const int nvec = C / 8;
+    const float invC = 1.0f / (float)C;
+    for (long long row = wave * rpw + lane / LPR; row < (rows + rpw - 1) / rpw * rpw; row += nwaves * rpw) {
+        const bool rok = row < rows;
+        float xv[NV][8], gv[NV][8];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = sub + i * LPR;
+            const bool ok = rok && v < nvec;
+            u32x4 xr{0, 0, 0, 0}, gr{0, 0, 0, 0};
+            if (ok) {
+                xr = *((const u32x4*)(x + (size_t)row * C) + v);
+                gr = *((const u32x4*)(dy + (size_t)row * C) + v);
+            }
+            unpack16<T>(xr, xv[i]);
+            unpack16<T>(gr, gv[i]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                s += xv[i][e];
+                gv[i][e] *= ok ? gamma[v * 8 + e] : 0.f;
+            }
+        }
+        for (int o = LPR >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float mean = s * invC;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const bool ok = sub + i * LPR < nvec;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { xv[i][e] = ok ? xv[i][e] - mean : 0.f; q = fmaf(xv[i][e], xv[i][e], q); }
+        }
+        for (int o = LPR >> 1; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        const float rstd = 1.0f / sqrtf(q * invC + eps);
+        float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { xv[i][e] *= rstd; m1 += gv[i][e]; m2 = fmaf(gv[i][e], xv[i][e], m2); }
+        for (int o = LPR >> 1; o > 0; o >>= 1) { m1 += __shfl_xor(m1, o); m2 += __shfl_xor(m2, o); }
+        m1 *= invC; m2 *= invC;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = sub + i * LPR;
+            if (!(rok && v < nvec)) continue;
+            float out[8], av[8];
+            if (add) unpack16<T>(*((const u32x4*)(add + (size_t)row * C) + v), av);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) out[e] = rstd * (gv[i][e] - m1 - xv[i][e] * m2) + (add ? av[e] : 0.f);
+            *((u32x4*)(dx + (size_t)row * C) + v) = pack16<T>(out);
+        }
+    }
+}
+template <typename T>
+static bool layernorm_bwd16_launch(const void* dy, const void* x, const float* gamma, const void* add, void* dx, long long rows, int c,
+                                   float eps, hipStream_t st) {
+    if constexpr (sizeof(T) != 2) return false;
+    else {
+        if (c % 8 || c > 2048 || (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)add) & 15)) return false;
+        const int nvec = c / 8;
+        int lpr = 1;
+        while (lpr < nvec && lpr < 64) lpr <<= 1;
+        const int nv = (nvec + lpr - 1) / lpr;                 // 1, 2 or (3,) 4
+        const long long nw = (rows + (64 / lpr) - 1) / (64 / lpr);
+        const long long blocks = (nw + 3) / 4;
+        const int grid = (int)(blocks < 16384 ? blocks : 16384);
+        if (nv == 1) layernorm_bwd16_kernel<T, 1><<<grid, 256, 0, st>>>((const T*)dy, (const T*)x, gamma, (const T*)add, (T*)dx, rows, c, eps, lpr);
+        else if (nv == 2) layernorm_bwd16_kernel<T, 2><<<grid, 256, 0, st>>>((const T*)dy, (const T*)x, gamma, (const T*)add, (T*)dx, rows, c, eps, lpr);
+        else layernorm_bwd16_kernel<T, 4><<<grid, 256, 0, st>>>((const T*)dy, (const T*)x, gamma, (const T*)add, (T*)dx, rows, c, eps, lpr);
+        return true;
+    }
+}
 extern "C" int advs_layernorm_bwd(const void* dy, const void* x, const float* gamma, const void* add, void* dx, long long rows,
                                   int c, float eps, int dtype, void* stream) {
     ADVS_REQUIRE(dtype_ok(dtype), "advs_layernorm_bwd: unknown dtype code %d", dtype);
     ADVS_REQUIRE(dy && x && gamma && dx && rows > 0 && c > 0, "layernorm_bwd: bad args");
+    if (dtype != ADVS_F32) {
+        const bool done = dtype == ADVS_BF16 ? layernorm_bwd16_launch<BF16>(dy, x, gamma, add, dx, rows, c, eps, (hipStream_t)stream)
+                                             : layernorm_bwd16_launch<F16>(dy, x, gamma, add, dx, rows, c, eps, (hipStream_t)stream);
+        if (done) { ADVS_CHECK_LAUNCH("layernorm_bwd"); return ADVS_OK; }
+    }
     const long long blocks = (rows + 3) / 4;
     const int grid = (int)(blocks < 8192 ? blocks : 8192);
     ADVS_SWITCH_T(dtype, layernorm_bwd_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T*)dy, (const T*)x, gamma, (const T*)add,

@@ -389,6 +389,34 @@ def test_vit_backward_pieces_match_autograd():
 
 
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("rows,C,with_add", [(37, 64, True), (101, 128, False), (50, 96, True), (23, 768, True), (9, 1024, False),
+                                             (5, 1536, True), (6, 2048, True), (7, 2056, False), (11, 100, True)])
+def test_layernorm_backward_16bit(prec, rows, C, with_add):
+    """LayerNorm gradient in 16-bit storage (csrc/vit_grad.hip: the register-resident kernel for C % 8 == 0 and C <= 2048 -- 8 to 64
+    lanes per row, 1 to 4 vectors per lane, ragged row counts -- and the generic kernel otherwise) against fp32 autograd on the same
+    rounded inputs, within 1.5 ulp of the storage type relative to the largest component of the row."""
+    lib = OneOp(prec, 1).b.lib
+    td = torch.bfloat16 if prec == "bf16" else torch.float16
+    code = 1 if prec == "bf16" else 2
+    s = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(rows * 7 + C)
+    x16 = (torch.randn(rows, C, generator=g) * 1.5 + 0.3).to(td)
+    dy16 = torch.randn(rows, C, generator=g).to(td)
+    add16 = torch.randn(rows, C, generator=g).to(td)
+    gam, bet = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    x = x16.float().requires_grad_(True)
+    F.layer_norm(x, (C,), gam, bet, 1e-6).backward(dy16.float())
+    ref = x.grad + (add16.float() if with_add else 0)
+    dx = torch.full((rows, C), 3.0, dtype=td, device=dev())
+    args = [x16.to(dev()), dy16.to(dev()), gam.to(dev()), add16.to(dev())]
+    assert lib.advs_layernorm_bwd(ptr(args[1]), ptr(args[0]), ptr(args[2]), ptr(args[3]) if with_add else 0, ptr(dx), rows, C, 1e-6, code, s) == 0
+    torch.cuda.synchronize()
+    ulp = 2.0 ** -8 if prec == "bf16" else 2.0 ** -11
+    err = (dx.float().cpu() - ref).abs().max(1).values
+    assert (err <= 1.5 * ulp * ref.abs().max(1).values + 1e-6).all(), (err.max().item(), ref.abs().max().item())
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
 @pytest.mark.parametrize("n", [8 * 1000, 8 * 37 + 3])
 def test_gelu_16bit_both_ways(prec, n):
     """Exact-GELU forward and gradient in 16-bit storage (csrc/vit_grad.hip: the vectorised kernel with the Abramowitz-Stegun erf
