@@ -110,6 +110,12 @@ SIGNATURES = {
     "advs_dwconv2d_bwd": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "advs_depth_to_space2": [vp, vp, i32, i32, i32, i32, i32, vp],
     "advs_avgpool_bwd": [vp, vp, i32, i32, i32, i32, vp],
+    "advs_silu": [vp, vp, vp, C.c_longlong, i32, vp],
+    "advs_silu_bwd": [vp, vp, vp, C.c_longlong, i32, vp],
+    "advs_dwconv2d_bwd_strided": [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    "advs_channel_dot": [vp, vp, vp, i32, i32, i32, i32, vp],
+    "advs_sigmoid_gate_bwd": [vp, vp, vp, C.c_longlong, vp],
+    "advs_se_scale_bwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "advs_unpatchify_padded": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "advs_event_record": [vp, vp],
     "advs_event_elapsed_ms": [vp, vp, C.POINTER(f32)],

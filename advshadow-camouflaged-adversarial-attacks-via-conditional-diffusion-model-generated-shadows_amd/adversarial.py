@@ -9,8 +9,9 @@ update and clamps are ``advs_iga_step`` / ``advs_perturb_clamp01``.  There is no
 
 The classifier must be (or wrap, as ``classifier.model``) a victim with a backward plan: ``advshadow_amd.victims.ResNet50``
 (the architecture of ddim2/test.py:22-36), ``victims.VGG``, ``victims.ViTVictim`` / ``victims.Dinov2Victim`` (the HF ViT / DINOv2 of ASR_fast.py:47-58: LayerNorm, GELU and
-attention gradients in ``csrc/vit_grad.hip`` and ``csrc/attention_bwd.hip``) ``victims.ConvNeXtVictim`` (ASR_fast.py:21-26: ``csrc/convnext_grad.hip``) or ``victims.SwinVictim`` (ASR_fast.py:27-32: the
-window attention gradient with its score bias); the fastai learner pickle of tools/train_shadow.py:50 is not loadable here.
+attention gradients in ``csrc/vit_grad.hip`` and ``csrc/attention_bwd.hip``) ``victims.ConvNeXtVictim`` (ASR_fast.py:21-26: ``csrc/convnext_grad.hip``), ``victims.SwinVictim`` (ASR_fast.py:27-32: the window
+attention gradient with its score bias) or ``victims.EfficientNetV2S`` (ASR_fast.py:59-65: ``csrc/effnet_grad.hip``) -- every victim
+family of ASR_fast.py; the fastai learner pickle of tools/train_shadow.py:50 is not loadable here.
 """
 import ctypes as C
 
@@ -26,7 +27,7 @@ def _victim(classifier):
     model = getattr(classifier, "model", classifier)
     if not hasattr(model, "grad_engine"):
         raise _lib.AdvsError(f"{type(model).__name__} has no HIP backward plan: the gradient attack needs an "
-                             "advshadow_amd.victims.ResNet50, VGG, ViTVictim, Dinov2Victim, ConvNeXtVictim or SwinVictim (there is no autograd fallback)")
+                             "advshadow_amd.victims.ResNet50, VGG, ViTVictim, Dinov2Victim, ConvNeXtVictim, SwinVictim or EfficientNetV2S (there is no autograd fallback)")
     return model
 
 

@@ -1813,7 +1813,7 @@ _EFFNETV2_S = [("fused", 1, 3, 1, 24, 24, 2), ("fused", 4, 3, 2, 24, 48, 4), ("f
                ("mb", 4, 3, 2, 64, 128, 6), ("mb", 6, 3, 1, 128, 160, 9), ("mb", 6, 3, 2, 160, 256, 15)]
 
 
-class EfficientNetV2S(nn.Module):
+class EfficientNetV2S(_InputGradient, nn.Module):
     """torchvision ``efficientnet_v2_s`` with ``classifier[1] = Linear(1280, 37)`` (ASR_fast.py:59-65) on the HIP
     kernels: BatchNorm (eps 1e-3) folded into every conv, FusedMBConv = 3x3 GEMM (+1x1 projection), MBConv = 1x1
     expansion -> depthwise 3x3 (+SiLU) -> squeeze-excitation (pool, two tiny Linears, per-channel scale) -> 1x1
@@ -1925,6 +1925,65 @@ class EfficientNetV2S(nn.Module):
             self._engines[(batch, dt)] = eng
         return eng
 
+    # ---- backward to the image (the gradient attack of tools/train_shadow.py:177-221 with this victim) ------------------
+    def packed_grad_weights(self, dt):
+        """Weights of the data-gradient convs: BatchNorm folded and channels zero-padded as forwards, then 1x1 transposed,
+        3x3 transposed and flipped; the classifier weight transposed."""
+        ver = self._version()
+        hit = self._packed.get(("grad", dt))
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        self.packed_weights(dt)
+        dev = next(self.parameters()).device
+        sd = {k: v.detach() for k, v in self.state_dict().items()}
+        pad = self._pad8
+        G = {}
+
+        def fold(p):
+            scale = sd[p + ".1.weight"].float() / torch.sqrt(sd[p + ".1.running_var"].float() + 1e-3)
+            return sd[p + ".0.weight"].float() * scale[:, None, None, None]
+
+        def gemmT(p, name):
+            w = fold(p)
+            co, ci = pad(w.shape[0]), pad(w.shape[1])
+            wp = torch.zeros((co, ci) + tuple(w.shape[2:]), device=dev)
+            wp[:w.shape[0], :w.shape[1]] = w
+            G[name] = pack_conv_weight(wp.permute(1, 0, 2, 3).flip(2, 3).contiguous(), dt)
+
+        w0 = fold("features.0")
+        c0 = pad(w0.shape[0])
+        ws = torch.zeros((c0, 3, 3, 3), device=dev); ws[:w0.shape[0]] = w0
+        G["stem.w"] = ws.contiguous()                         # advs_conv_stem_bwd reads the forward OIHW weight
+        for item in self.layout[1:]:
+            if item[0] == "cna":
+                gemmT(item[1], "headT")
+                continue
+            kind, p, e, k, st, ci, co = item
+            gemmT(p + ".block.0", p + ".c0T")
+            if kind == "fused":
+                if e != 1:
+                    gemmT(p + ".block.1", p + ".c1T")
+            else:
+                gemmT(p + ".block.3", p + ".c3T")
+                for n in ("fc1", "fc2"):                     # the squeeze-excitation Linears backwards: advs_linear_f32 on W'
+                    wse = sd[f"{p}.block.2.{n}.weight"].float()
+                    G[f"{p}.{n}T"] = wse.reshape(wse.shape[0], -1).t().contiguous()
+        G["cls.wT"] = sd["classifier.1.weight"].float().t().contiguous()
+        self._packed[("grad", dt)] = (ver, G)
+        return G
+
+    def grad_engine(self, batch, size=None, dtype=None):
+        """Static plan of forward + backward-to-the-image (d cross_entropy / d input) for [batch,3,S,S] inputs."""
+        if size is not None and size != self.image_size:
+            raise ValueError(f"EfficientNetV2S was built for {self.image_size}x{self.image_size} inputs, not {size}")
+        dt = dtype_code(dtype if dtype is not None else self.compute_dtype)
+        W, G = self.packed_weights(dt), self.packed_grad_weights(dt)
+        eng = self._engines.get(("grad", batch, dt))
+        if eng is None:
+            eng = _EffNetGradEngine(self, W, G, batch, dt)
+            self._engines[("grad", batch, dt)] = eng
+        return eng
+
     def forward(self, x):
         if x.shape[2] != self.image_size or x.shape[3] != self.image_size:
             raise ValueError(f"EfficientNetV2S was built for {self.image_size}x{self.image_size} inputs, got {tuple(x.shape[2:])}")
@@ -1938,6 +1997,167 @@ class EfficientNetV2S(nn.Module):
         cur.wait_stream(eng.stream)
         out.record_stream(cur)
         return out
+
+
+class _EffNetGradEngine:
+    """EfficientNetV2-S forward with every SiLU as its own pass (the pre-activations are what the reverse sweep needs), then backwards:
+      FusedMBConv: d pre = d m * silu'(pre), d in = conv3x3'(d pre) (zero insertion in front of it for stride 2) (+ d out for the residual);
+      MBConv: d sc = d out W3';  gs = sum_p d sc * d;  SE backwards (advs_se_mlp_bwd);  d pre_dw = (d sc * s + d pooled / HW) * silu'(pre_dw);
+              d m = depthwise'(d pre_dw);  d in = (d m * silu'(pre_m)) W0' (+ d out);
+      head conv, average pool and classifier as in the other victims; BatchNorm (eval) is folded into the weights both ways."""
+
+    def __init__(self, model, W, G, batch, dt):
+        dev = next(model.parameters()).device
+        self.model, self.stream = model, torch.cuda.Stream(device=dev)
+        S, pad = model.image_size, model._pad8
+        with torch.cuda.device(dev):
+            bld = Builder(dev, dt, self.stream, batch)
+            lib, plan = bld.lib, bld.plan
+            self.x = torch.zeros((batch, 3, S, S), dtype=torch.float32, device=dev)
+            self.labels = torch.zeros((batch,), dtype=torch.int64, device=dev)
+            self.grad = torch.zeros((batch, 3, S, S), dtype=torch.float32, device=dev)
+
+            def silu(pre, add=None):
+                y = bld.buf(tuple(pre.shape))
+                plan.add(lib.advs_silu, ptr(pre), ptr(add), ptr(y), pre.numel(), dt, keep=(pre, add, y))
+                return y
+
+            def silu_bwd(pre, dy):
+                dx = bld.buf(tuple(pre.shape))
+                plan.add(lib.advs_silu_bwd, ptr(pre), ptr(dy), ptr(dx), pre.numel(), dt, keep=(pre, dy, dx))
+                return dx
+
+            def zero_insert(t, hh, ww):
+                z = bld.buf((batch, hh, ww, t.shape[3]))
+                plan.add(lib.advs_zero_insert2x, ptr(t), ptr(z), batch, t.shape[1], t.shape[2], t.shape[3], hh, ww, dt, keep=(t, z))
+                bld.free(t)
+                return z
+
+            # ---- forward
+            c0 = W["stem.b"].numel()
+            side = (S + 2 - 3) // 2 + 1
+            pre0 = bld.buf((batch, side, side, c0))
+            plan.add(lib.advs_conv_stem, ptr(self.x), ptr(W["stem.w"]), ptr(W["stem.b"]), ptr(pre0), batch, 3, S, S, c0, 3, 2, 1,
+                     _lib.ACT["none"], dt, keep=(self.x, pre0))
+            h = silu(pre0)
+            tape = [("stem", pre0, c0)]
+            for item in model.layout[1:]:
+                if item[0] == "cna":
+                    preh = bld.conv(h, W["head.w"], model.last, bias=W["head.b"], ksize=1, pad=0)
+                    bld.free(h)
+                    h = silu(preh)
+                    tape.append(("head", preh))
+                    continue
+                kind, p, e, k, st, ci, co = item
+                has_res = st == 1 and ci == co
+                cop, cep = pad(co), pad(ci * e)
+                hin_shape = tuple(h.shape)
+                if kind == "fused" and e == 1:
+                    pre = bld.conv(h, W[p + ".c0.w"], cop, bias=W[p + ".c0.b"], stride=st)
+                    new = silu(pre, h if has_res else None)
+                    tape.append(("fused1", p, pre, st, has_res, hin_shape))
+                elif kind == "fused":
+                    pre = bld.conv(h, W[p + ".c0.w"], cep, bias=W[p + ".c0.b"], stride=st)
+                    m = silu(pre)
+                    new = bld.conv(m, W[p + ".c1.w"], cop, bias=W[p + ".c1.b"], residual=h if has_res else None, ksize=1, pad=0)
+                    bld.free(m)
+                    tape.append(("fused", p, pre, st, has_res, hin_shape, cep))
+                else:
+                    prem = bld.conv(h, W[p + ".c0.w"], cep, bias=W[p + ".c0.b"], ksize=1, pad=0)
+                    m = silu(prem)
+                    si = m.shape[1]
+                    so = (si + 2 - 3) // st + 1
+                    pred = bld.buf((batch, so, so, cep))
+                    plan.add(lib.advs_dwconv2d, ptr(m), ptr(W[p + ".dw.w"]), ptr(W[p + ".dw.b"]), ptr(pred), batch, si, si, cep, k, st, dt,
+                             keep=(m, pred))
+                    bld.free(m)
+                    d = silu(pred)
+                    pooled = bld.buf((batch, cep), torch.float32)
+                    plan.add(lib.advs_global_avgpool, ptr(d), ptr(pooled), batch, so * so, cep, dt, keep=(d, pooled))
+                    z1 = bld.linear(pooled, W[p + ".fc1.w"], W[p + ".fc1.b"])
+                    s2 = bld.linear(z1, W[p + ".fc2.w"], W[p + ".fc2.b"], act_in="silu", act_out="sigmoid")
+                    sc = bld.buf((batch, so, so, cep))
+                    plan.add(lib.advs_scale_channels, ptr(d), ptr(s2), ptr(sc), batch, so * so, cep, dt, keep=(d, s2, sc))
+                    new = bld.conv(sc, W[p + ".c3.w"], cop, bias=W[p + ".c3.b"], residual=h if has_res else None, ksize=1, pad=0)
+                    bld.free(sc)
+                    tape.append(("mb", p, prem, pred, d, z1, s2, k, st, has_res, hin_shape, cep, si, so))
+                bld.free(h)
+                h = new
+            hw_last = h.shape[1] * h.shape[2]
+            pooled = bld.buf((batch, model.last), torch.float32)
+            plan.add(lib.advs_global_avgpool, ptr(h), ptr(pooled), batch, hw_last, model.last, dt, keep=(h, pooled))
+            last_shape = tuple(h.shape)
+            bld.free(h)
+            self.logits = bld.linear(pooled, W["cls.w"], W["cls.b"])
+            # ---- backward
+            K = self.logits.shape[1]
+            gl = bld.buf((batch, K), torch.float32)
+            plan.add(lib.advs_softmax_ce_grad, ptr(self.logits), ptr(self.labels), ptr(gl), batch, K, 1.0, keep=(self.logits, self.labels, gl))
+            gp = bld.linear(gl, G["cls.wT"], None)
+            g = bld.buf(last_shape)
+            plan.add(lib.advs_avgpool_bwd, ptr(gp), ptr(g), batch, hw_last, model.last, dt, keep=(gp, g))
+            for rec in reversed(tape):
+                kind = rec[0]
+                if kind == "head":
+                    dpre = silu_bwd(rec[1], g)
+                    bld.free(g); bld.free(rec[1])
+                    g = bld.conv(dpre, G["headT"], pad(model.setting[-1][5]), ksize=1, pad=0)
+                    bld.free(dpre)
+                elif kind in ("fused1", "fused"):
+                    if kind == "fused1":
+                        _, p, pre, st, has_res, hin_shape = rec
+                        dm = g
+                    else:
+                        _, p, pre, st, has_res, hin_shape, cep = rec
+                        dm = bld.conv(g, G[p + ".c1T"], cep, ksize=1, pad=0)
+                    dpre = silu_bwd(pre, dm)
+                    if dm is not g:
+                        bld.free(dm)
+                    bld.free(pre)
+                    if st == 2:
+                        dpre = zero_insert(dpre, hin_shape[1], hin_shape[2])
+                    din = bld.conv(dpre, G[p + ".c0T"], hin_shape[3], residual=g if has_res else None, ksize=3, stride=1, pad=1)
+                    bld.free(dpre); bld.free(g)
+                    g = din
+                elif kind == "mb":
+                    _, p, prem, pred, d, z1, s2, k, st, has_res, hin_shape, cep, si, so = rec
+                    dsc = bld.conv(g, G[p + ".c3T"], cep, ksize=1, pad=0)
+                    gs = bld.buf((batch, cep), torch.float32)
+                    plan.add(lib.advs_channel_dot, ptr(dsc), ptr(d), ptr(gs), batch, so * so, cep, dt, keep=(dsc, d, gs))
+                    dz2 = bld.buf((batch, cep), torch.float32)
+                    plan.add(lib.advs_sigmoid_gate_bwd, ptr(gs), ptr(s2), ptr(dz2), batch * cep, keep=(gs, s2, dz2))
+                    da1 = bld.linear(dz2, G[p + ".fc2T"], None)                            # [B, sq]
+                    dz1 = bld.buf(tuple(da1.shape), torch.float32)
+                    plan.add(lib.advs_silu_bwd, ptr(z1), ptr(da1), ptr(dz1), da1.numel(), _lib.F32, keep=(z1, da1, dz1))
+                    dpool = bld.linear(dz1, G[p + ".fc1T"], None)                          # [B, cep]
+                    dpd = bld.buf(tuple(pred.shape))
+                    plan.add(lib.advs_se_scale_bwd, ptr(dsc), ptr(s2), ptr(dpool), ptr(pred), ptr(dpd), batch, so * so, cep, dt,
+                             keep=(dsc, s2, dpool, pred, dpd))
+                    bld.free(dsc); bld.free(pred); bld.free(d)
+                    dm = bld.buf((batch, si, si, cep))
+                    plan.add(lib.advs_dwconv2d_bwd_strided, ptr(dpd), ptr(W[p + ".dw.w"]), ptr(dm), batch, si, si, cep, k, st, dt, keep=(dpd, dm))
+                    bld.free(dpd)
+                    dprem = silu_bwd(prem, dm)
+                    bld.free(dm); bld.free(prem)
+                    din = bld.conv(dprem, G[p + ".c0T"], hin_shape[3], residual=g if has_res else None, ksize=1, pad=0)
+                    bld.free(dprem); bld.free(g)
+                    g = din
+                else:
+                    _, pre0, c0 = rec
+                    dpre = silu_bwd(pre0, g)
+                    bld.free(g)
+                    plan.add(lib.advs_conv_stem_bwd, ptr(dpre), ptr(G["stem.w"]), ptr(self.grad), batch, 3, S, S, c0, 3, 2, 1, dt,
+                             keep=(dpre, self.grad))
+            self.plan, self.captured = plan, False
+            torch.cuda.synchronize(dev)
+
+    def run(self):
+        if self.model.use_graph and not self.captured:
+            self.plan.run_eager()
+            self.stream.synchronize()
+            self.plan.capture()
+            self.captured = True
+        self.plan.run()
 
 
 class _EffNetEngine:

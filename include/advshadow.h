@@ -263,6 +263,21 @@ int advs_dwconv2d_bwd(const void* dy, const float* w_taps_c, const void* add, vo
 int advs_depth_to_space2(const void* x, void* y, int b, int h, int w, int c, int dtype, void* stream);
 /* Gradient of advs_global_avgpool: out[b][p][:] = g[b][:] / hw (g f32).                                                            */
 int advs_avgpool_bwd(const float* g, void* out, int b, int hw, int c, int dtype, void* stream);
+/* ---- EfficientNetV2-S victim backwards (torchvision efficientnet_v2_s of ASR_fast.py:59-65; csrc/effnet_grad.hip) ---------------
+ * SiLU as its own pass (y = silu(x) + add, add may be NULL) and its gradient from the PRE-activation: dx = dy * silu'(x_pre).          */
+int advs_silu(const void* x, const void* add, void* y, long long n, int dtype, void* stream);
+int advs_silu_bwd(const void* x_pre, const void* dy, void* dx, long long n, int dtype, void* stream);
+/* Data gradient of advs_dwconv2d for stride 1 or 2: dx [b][h][w][c] (the conv's input size) from dy at the output size.             */
+int advs_dwconv2d_bwd_strided(const void* dy, const float* w_taps_c, void* dx, int b, int h, int w, int c, int ksize, int stride,
+                              int dtype, void* stream);
+/* out[b][c] = sum_p a[b][p][c] * bb[b][p][c] (f32): the gradient reaching a squeeze-excitation scale.                               */
+int advs_channel_dot(const void* a, const void* bb, float* out, int b, int hw, int c, int dtype, void* stream);
+/* Gradient through the squeeze-excitation gate s = sigmoid(z2): out = gs * s * (1 - s), f32 vectors of n elements; the block's two
+ * Linear layers run backwards as advs_linear_f32 on transposed weights with advs_silu_bwd (f32) between them.                      */
+int advs_sigmoid_gate_bwd(const float* gs, const float* s, float* out, long long n, void* stream);
+/* out = (dsc * s[b][c] + dpooled[b][c] / hw) * silu'(pre): the gradient at the depthwise conv's pre-activation through y = silu(pre) * s. */
+int advs_se_scale_bwd(const void* dsc, const float* s, const float* dpooled, const void* pre, void* out, int b, int hw, int c,
+                      int dtype, void* stream);
 /* Gradient of advs_cls_mean_rows_f32 (the DINOv2 head input, ASR_fast.py:47-58 with a Dinov2 checkpoint): dst[b][0][:] = src[b][0..c),
  * dst[b][1..np][:] = src[b][c..2c) / np; src f32 [b][2c], dst [b][n_pad][c] in the compute dtype, other rows untouched.            */
 int advs_scatter_cls_mean(const float* src, void* dst, int b, int n_pad, int np, int c, int dtype, void* stream);

@@ -643,6 +643,128 @@ def test_swin_input_gradient_matches_transformers_autograd(prec, bound):
     assert torch.equal(again, grad)
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16"])
+def test_efficientnet_backward_pieces(prec):
+    """The non-GEMM gradient kernels of csrc/effnet_grad.hip and csrc/convnext_grad.hip against torch autograd on the same rounded
+    inputs: SiLU both ways, the depthwise gradient (stride 1 with the residual stream, stride 2, 3x3 and 7x7), depth-to-space, the
+    average pool's broadcast, the channel dot product and the squeeze-excitation block backwards."""
+    lib = OneOp(prec, 1).b.lib
+    td = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[prec]
+    code = {"fp32": 0, "bf16": 1, "fp16": 2}[prec]
+    ulp = {"fp32": 2.0 ** -22, "bf16": 2.0 ** -8, "fp16": 2.0 ** -11}[prec]
+    s = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(41)
+    r = lambda t: t.to(td).float()
+    close = lambda got, ref, k=2.0: (got.float().cpu() - ref).abs().max().item() <= k * ulp * max(1.0, ref.abs().max().item())
+    # SiLU forward (+ add) and backward
+    n = 8 * 123
+    x, a, dy = r(torch.randn(n, generator=g) * 3), r(torch.randn(n, generator=g)), r(torch.randn(n, generator=g))
+    xr = x.clone().requires_grad_(True)
+    y = F.silu(xr) + a
+    y.backward(dy)
+    xd, ad, dyd = (t.to(td).to(dev()) for t in (x, a, dy))
+    yd, dxd = torch.empty_like(xd), torch.empty_like(xd)
+    assert lib.advs_silu(ptr(xd), ptr(ad), ptr(yd), n, code, s) == 0 and lib.advs_silu_bwd(ptr(xd), ptr(dyd), ptr(dxd), n, code, s) == 0
+    torch.cuda.synchronize()
+    assert close(yd, y.detach()) and close(dxd, xr.grad)
+    # depthwise conv gradients: NHWC tensors, weights [k*k][C]
+    for k, st, H in ((3, 1, 10), (3, 2, 10), (7, 1, 9), (3, 2, 7)):
+        B, C = 2, 16
+        w = torch.randn(C, 1, k, k, generator=g) * 0.3
+        xin = r(torch.randn(B, C, H, H, generator=g)).requires_grad_(True)
+        out = F.conv2d(xin, w, stride=st, padding=k // 2, groups=C)
+        gy = r(torch.randn(out.shape, generator=g))
+        addt = r(torch.randn(B, C, H, H, generator=g))
+        out.backward(gy)
+        wt = w.reshape(C, k * k).t().contiguous().to(dev())
+        gyd = gy.permute(0, 2, 3, 1).contiguous().to(td).to(dev())
+        dxd = torch.empty(B, H, H, C, dtype=td, device=dev())
+        assert lib.advs_dwconv2d_bwd_strided(ptr(gyd), ptr(wt), ptr(dxd), B, H, H, C, k, st, code, s) == 0
+        torch.cuda.synchronize()
+        assert close(dxd.permute(0, 3, 1, 2), xin.grad, 4.0), (k, st)
+        if st == 1:
+            addd = addt.permute(0, 2, 3, 1).contiguous().to(td).to(dev())
+            assert lib.advs_dwconv2d_bwd(ptr(gyd), ptr(wt), ptr(addd), ptr(dxd), B, H, H, C, k, code, s) == 0
+            torch.cuda.synchronize()
+            assert close(dxd.permute(0, 3, 1, 2), xin.grad + addt, 4.0), (k, "add")
+    # depth-to-space is the inverse of space-to-depth; the pooled gradient is a broadcast
+    B, H, C = 2, 6, 16
+    t = r(torch.randn(B, H, H, C, generator=g)).to(td).to(dev())
+    s2d, back = torch.empty(B, H // 2, H // 2, 4 * C, dtype=td, device=dev()), torch.empty_like(t)
+    assert lib.advs_space_to_depth2(ptr(t), ptr(s2d), B, H, H, C, code, s) == 0 and lib.advs_depth_to_space2(ptr(s2d), ptr(back), B, H, H, C, code, s) == 0
+    gp = torch.randn(B, C, generator=g).to(dev())
+    bro = torch.empty(B, H * H, C, dtype=td, device=dev())
+    assert lib.advs_avgpool_bwd(ptr(gp), ptr(bro), B, H * H, C, code, s) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(back, t) and close(bro, (gp.cpu() / (H * H))[:, None, :].expand(B, H * H, C))
+    # squeeze-excitation backwards: y = d * sigmoid(W2 silu(W1 mean(d) + b1) + b2), d = silu(pre)
+    B, HW, C, SQ = 3, 20, 24, 5
+    pre = r(torch.randn(B, HW, C, generator=g)).requires_grad_(True)
+    w1, b1 = torch.randn(SQ, C, generator=g) * 0.3, torch.randn(SQ, generator=g) * 0.1
+    w2, b2 = torch.randn(C, SQ, generator=g) * 0.3, torch.randn(C, generator=g) * 0.1
+    d = F.silu(pre)
+    z1 = d.mean(1) @ w1.t() + b1
+    sg = torch.sigmoid(F.silu(z1) @ w2.t() + b2)
+    yv = d * sg[:, None, :]
+    dsc = r(torch.randn(B, HW, C, generator=g))
+    yv.backward(dsc)
+    dev_ = lambda t_: t_.contiguous().to(dev())
+    dscd, dd, pred = dev_(dsc.to(td)), dev_(d.detach().to(td)), dev_(pre.detach().to(td))
+    gs = torch.empty(B, C, device=dev())
+    assert lib.advs_channel_dot(ptr(dscd), ptr(dd), ptr(gs), B, HW, C, code, s) == 0
+    torch.cuda.synchronize()
+    ref_gs = (dsc * d.detach().to(td).float()).sum(1)
+    assert (gs.cpu() - ref_gs).abs().max().item() < 1e-4 * max(1.0, ref_gs.abs().max().item())
+    sgd, z1d = dev_(sg.detach()), dev_(z1.detach())
+    dz2 = torch.empty(B, C, device=dev())
+    assert lib.advs_sigmoid_gate_bwd(ptr(gs), ptr(sgd), ptr(dz2), B * C, s) == 0
+    torch.cuda.synchronize()
+    da1 = dz2 @ dev_(w2)                                                   # the engine runs these two as advs_linear_f32 on W'
+    sz = torch.sigmoid(z1d)
+    dz1 = da1 * sz * (1 + z1d * (1 - sz))                                  # (advs_silu_bwd in f32 there; its own check is above)
+    dpool = (dz1 @ dev_(w1)).contiguous()
+    outd = torch.empty(B, HW, C, dtype=td, device=dev())
+    assert lib.advs_se_scale_bwd(ptr(dscd), ptr(sgd), ptr(dpool), ptr(pred), ptr(outd), B, HW, C, code, s) == 0
+    torch.cuda.synchronize()
+    assert close(outd, pre.grad, 6.0 if prec != "fp32" else 64.0), (outd.float().cpu() - pre.grad).abs().max().item()
+
+
+_EFF_SHALLOW = [("fused", 1, 3, 1, 24, 24, 1), ("fused", 4, 3, 2, 24, 48, 2), ("mb", 4, 3, 2, 48, 64, 2), ("mb", 6, 3, 1, 64, 64, 2)]
+
+
+@pytest.mark.parametrize("prec,setting,bound", [("fp32", None, 1e-3), ("fp32", _EFF_SHALLOW, 1e-4), ("bf16", _EFF_SHALLOW, 0.05),
+                                                ("fp16", _EFF_SHALLOW, 0.01)])
+def test_efficientnet_input_gradient_matches_restatement_autograd(prec, setting, bound):
+    """d cross_entropy / d input of the EfficientNetV2-S victim (SiLU gradients from retained pre-activations, FusedMBConv with the
+    zero-insertion form of the stride-2 3x3 gradient, MBConv with the strided depthwise gradient and the squeeze-excitation block
+    backwards, BatchNorm folded) against autograd over oracle/victims.py's restatement at 64 px: the full 40-block network in fp32, and
+    a 7-block one (every block kind, both strides) in all dtypes -- the randomly initialised full network amplifies a 16-bit
+    rounding of its activations into a 7 % logit error (the forward test's bound is 15 %), which says nothing about the kernels.
+    PARITY UNPINNED like the forward (torchvision is absent); replays bit-identical."""
+    from advshadow_amd.victims import EfficientNetV2S
+    from oracle import victims as ov
+    kw = {} if setting is None else dict(setting=setting, last_channel=256)
+    okw = () if setting is None else (setting, 256)
+    sd = ov.effnetv2_init(3, 37, *okw)
+    net = EfficientNetV2S(37, image_size=64, compute_dtype=prec, **kw)
+    net.load_state_dict(sd)
+    net = net.to("cuda").eval()
+    x = torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(27))
+    labels = torch.tensor([5, 30])
+    xr = x.clone().requires_grad_(True)
+    ref_logits = ov.effnetv2_forward.__wrapped__(sd, xr, *okw)           # the restatement without its no_grad decorator
+    F.cross_entropy(ref_logits, labels, reduction="sum").backward()
+    logits, grad = net.input_gradient(x.cuda(), labels.cuda())
+    scale = xr.grad.abs().max().item()
+    err = (grad.cpu() - xr.grad).abs().max().item()
+    print("efficientnet input gradient:", prec, "full" if setting is None else "shallow", "max", scale, "err", err)
+    assert err < bound * scale, (err, scale)
+    if prec == "fp32":
+        assert (logits.cpu() - ref_logits.detach()).abs().max().item() < 5e-4 * max(1.0, ref_logits.abs().max().item())
+    _, again = net.input_gradient(x.cuda(), labels.cuda())
+    assert torch.equal(again, grad)
+
+
 def test_vit_victim_drives_the_gradient_attack():
     """apply_shadow(classifier=ViTVictim) (train_shadow.py:242-266 with config 4's victim): the composite stays within epsilon * mask of the
     closed-form shadow and differs from it; fp16 (config 4's dtype) agrees with fp32 in the sign of most gradient components."""

@@ -2,7 +2,7 @@
 """Gradient attack throughput (not the headline metric): images/s of the 20-iteration iterative-gradient
 perturbation (tools/train_shadow.py:177-221) on the ResNet-50 victim, and the time of one forward + backward-to-image
 replay.  GPU box only.
-    python tools/bench_attack.py [--victim resnet50|vgg16|vit|dinov2|convnext|swin] [--size 224] [--batch 32] [--iters 20] [--dtype fp32|bf16] [--cpu-images 1]
+    python tools/bench_attack.py [--victim resnet50|vgg16|vit|dinov2|convnext|swin|effnet] [--size 224] [--batch 32] [--iters 20] [--dtype fp32|bf16] [--cpu-images 1]
 ``--cpu-images N`` also times the CPU autograd oracle on N images (the reference's own code path, one image at a time).
 """
 import argparse
@@ -26,7 +26,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--dtype", default="fp32")
     ap.add_argument("--cpu-images", type=int, default=0)
-    ap.add_argument("--victim", default="resnet50", choices=["resnet50", "vgg16", "vit", "dinov2", "convnext", "swin"])
+    ap.add_argument("--victim", default="resnet50", choices=["resnet50", "vgg16", "vit", "dinov2", "convnext", "swin", "effnet"])
     a = ap.parse_args()
     torch.manual_seed(0)
     if a.victim == "vit":
@@ -41,6 +41,9 @@ def main():
     elif a.victim == "swin":
         from advshadow_amd.victims import SwinVictim
         net = SwinVictim(37, image_size=a.size, compute_dtype=a.dtype).to("cuda").eval()
+    elif a.victim == "effnet":
+        from advshadow_amd.victims import EfficientNetV2S
+        net = EfficientNetV2S(37, image_size=a.size, compute_dtype=a.dtype).to("cuda").eval()
     elif a.victim == "vgg16":
         from advshadow_amd.victims import VGG
         net = VGG(16, 37, compute_dtype=a.dtype).to("cuda").eval()
@@ -60,7 +63,7 @@ def main():
     dt = (time.perf_counter() - t0) / reps
     eng = net.grad_engine(a.batch, a.size)
     tot = bench.conv_profile(eng)
-    rec = {"workload": "iterative-gradient attack on " + {"vgg16": "VGG16", "vit": "ViT-B/16", "dinov2": "DINOv2-B/14", "convnext": "ConvNeXt-B", "swin": "Swin-B", "resnet50": "ResNet-50"}[a.victim], "size": a.size, "batch": a.batch, "iterations": a.iters,
+    rec = {"workload": "iterative-gradient attack on " + {"vgg16": "VGG16", "vit": "ViT-B/16", "dinov2": "DINOv2-B/14", "convnext": "ConvNeXt-B", "swin": "Swin-B", "effnet": "EfficientNetV2-S", "resnet50": "ResNet-50"}[a.victim], "size": a.size, "batch": a.batch, "iterations": a.iters,
            "dtype": a.dtype, "images_per_s": a.batch / dt, "s_per_batch": dt,
            "fwd_bwd_ms_by_kernel": {k: round(v[1], 3) for k, v in sorted(tot.items())},
            "fwd_bwd_ms_total": round(sum(v[1] for v in tot.values()), 3)}
