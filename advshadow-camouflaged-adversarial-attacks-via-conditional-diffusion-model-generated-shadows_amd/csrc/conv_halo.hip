@@ -228,12 +228,12 @@ conv3x3_halo_kernel(const ConvKP p) {
                 } else if (hn && t < 2) {                             // three halo pieces in each of taps 0 and 1
                     if (ks >= 1) issue_A(unit + 1, 3 * t + ks - 1);
                 }
-                __builtin_amdgcn_s_setprio(1);
+                // (no s_setprio around the MFMAs: with the fast epilogue in place raising the priority costs 2 % of the conv time,
+                // profiles/round2_halo512.txt (3))
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) Mma<T>::run(af[cur][i], bf[cur][j], acc[i][j]);
-                __builtin_amdgcn_s_setprio(0);
             }
         };
         tap(std::integral_constant<int, 0>{}); tap(std::integral_constant<int, 1>{}); tap(std::integral_constant<int, 2>{});
@@ -265,12 +265,10 @@ conv3x3_halo_kernel(const ConvKP p) {
                     if (ks == 2) { issue_A(unit + 1, 2); issue_A(unit + 1, 3); }
                     if (ks == 3) { issue_A(unit + 1, 4); issue_A(unit + 1, 5); }
                 }
-                __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) Mma<T>::run(af[cur][i], bf[cur][j], acc[i][j]);
-                __builtin_amdgcn_s_setprio(0);
             }
         }
     }
