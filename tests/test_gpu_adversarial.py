@@ -765,6 +765,54 @@ def test_efficientnet_input_gradient_matches_restatement_autograd(prec, setting,
     assert torch.equal(again, grad)
 
 
+@pytest.mark.parametrize("family", ["dinov2", "convnext", "swin", "effnet"])
+def test_every_victim_family_drives_the_gradient_attack(family):
+    """apply_shadow(classifier=...) / adversarial_perturbation_batch (train_shadow.py:177-266) with the victims that got their backward
+    plans in round 2: the adversarial composite stays within epsilon * mask of the closed-form shadow and differs from it, and the
+    batched perturbation lowers the victim's confidence in the true label on most images of a batch."""
+    from advshadow_amd import adversarial, victims
+    from oracle import victims as ov
+    if family == "dinov2":
+        hf = ov.hf_dinov2(5, seed=9, image_size=56, hidden_size=64, num_hidden_layers=2, num_attention_heads=4, patch_size=14, mlp_ratio=4)
+        net, S = victims.Dinov2Victim(5, hidden_size=64, num_hidden_layers=2, num_attention_heads=4, image_size=56, pos_grid=4), 56
+        net.load_state_dict(hf.state_dict())
+    elif family == "convnext":
+        cfg = dict(depths=[1, 1, 2, 1], hidden_sizes=[64, 128, 256, 512], image_size=64)
+        hf = ov.hf_convnext(5, seed=5, **cfg)
+        net, S = victims.ConvNeXtVictim(5, depths=cfg["depths"], dims=cfg["hidden_sizes"], image_size=64, head_norm_eps=1e-12), 64
+        net.load_state_dict(hf.state_dict())
+    elif family == "swin":
+        hf = ov.hf_swin(5, seed=7, image_size=64, patch_size=4, embed_dim=32, depths=[2, 2], num_heads=[2, 4], window_size=4)
+        net, S = victims.SwinVictim(5, embed_dim=32, depths=[2, 2], num_heads=[2, 4], window_size=4, image_size=64), 64
+        net.load_state_dict(hf.state_dict())
+    else:
+        setting = [("fused", 1, 3, 1, 24, 24, 1), ("fused", 4, 3, 2, 24, 48, 2), ("mb", 4, 3, 2, 48, 64, 2), ("mb", 6, 3, 1, 64, 64, 2)]
+        net, S = victims.EfficientNetV2S(5, setting=setting, last_channel=256, image_size=64), 64
+        net.load_state_dict(ov.effnetv2_init(3, 5, setting, 256))
+    net = net.to("cuda").eval()
+    g = torch.Generator().manual_seed(8)
+    img = torch.rand(3, S, S, generator=g)
+    fm = (torch.rand(1, S, S, generator=g) > 0.3).float()
+    plain = shadow.apply_shadow(img, (S * 0.45, S * 0.55), S * 0.2, fm, None, None, "cuda").cpu()
+    adv = shadow.apply_shadow(img, (S * 0.45, S * 0.55), S * 0.2, fm, net, torch.tensor([2]), "cuda").cpu()
+    assert (adv - plain).abs().max().item() <= 0.01 + 1e-6 and not torch.equal(adv, plain)
+    x = torch.rand(6, 3, S, S, generator=g).cuda()
+    with torch.no_grad():
+        out0 = net(x)
+        logits0 = (out0.logits if hasattr(out0, "logits") else out0).float()
+    lab = logits0.argmax(1)
+    masks = torch.ones(6, 1, S, S, device="cuda")
+    lab = (lab + 1) % logits0.shape[1]                                     # a label the victim does not predict yet: room to move
+    xa, pert = adversarial.adversarial_perturbation_batch(net, x, lab, masks, 0.05, 0.01, 10)
+    assert pert.abs().max().item() <= 0.05 + 1e-6 and (xa - (x + pert).clamp(0, 1)).abs().max().item() < 1e-6
+    with torch.no_grad():
+        out1 = net(xa)
+        logits1 = (out1.logits if hasattr(out1, "logits") else out1).float()
+    p0 = torch.softmax(logits0, 1).gather(1, lab[:, None])[:, 0]
+    p1 = torch.softmax(logits1, 1).gather(1, lab[:, None])[:, 0]
+    assert (p1 > p0).float().mean().item() >= 0.8, (p0.tolist(), p1.tolist())
+
+
 def test_vit_victim_drives_the_gradient_attack():
     """apply_shadow(classifier=ViTVictim) (train_shadow.py:242-266 with config 4's victim): the composite stays within epsilon * mask of the
     closed-form shadow and differs from it; fp16 (config 4's dtype) agrees with fp32 in the sign of most gradient components."""
