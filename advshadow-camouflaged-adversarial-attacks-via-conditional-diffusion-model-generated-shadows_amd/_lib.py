@@ -88,6 +88,8 @@ SIGNATURES = {
     "advs_softmax_ce_grad": [vp, vp, vp, i32, i32, f32, vp],
     "advs_relu_bwd": [vp, vp, vp, vp, C.c_longlong, i32, vp],
     "advs_zero_insert2x": [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    "advs_gather2x2": [vp, vp, i32, i32, i32, i32, i32, vp],
+    "advs_depth_to_space2_relu": [vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "advs_avgpool_bwd_relu": [vp, vp, vp, i32, i32, i32, i32, vp],
     "advs_maxpool3x3s2_bwd_relu": [vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "advs_maxpool2_bwd_relu": [vp, vp, vp, i32, i32, i32, i32, i32, vp],

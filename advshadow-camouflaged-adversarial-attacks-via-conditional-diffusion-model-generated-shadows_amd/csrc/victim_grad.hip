@@ -94,6 +94,73 @@ extern "C" int advs_zero_insert2x(const void* in, void* out, int b, int h, int w
     return ADVS_OK;
 }
 
+// ---------------------------------------------------------------- stride-2 3x3 data gradient without the zero insertion
+// A 3x3 / stride 2 / pad 1 conv's data gradient at input pixel (2i+a, 2j+b) only ever sees output pixels (i, j), (i, j+1), (i+1, j),
+// (i+1, j+1): parity a = 0 takes row i through tap ky = 1, parity a = 1 takes rows i and i+1 through ky = 2 and ky = 0 (likewise
+// columns).  So the gradient of all four parities is ONE 1x1 GEMM over the gathered quadruple, [4 C'] -> [4 C] with the host-packed
+// block matrix (9 of its 16 blocks are non-zero: 4 C C' MACs per output pixel quadruple instead of the 9 C C' per pixel = 36 per
+// quadruple of the zero-insertion form), followed by a depth-to-space interleave that also applies the ReLU mask.
+// out[b][i][j][q*c .. +c) = in[b][i + (q >> 1)][j + (q & 1)][:]  (0 beyond the last row / column)
+template <typename T>
+__global__ void gather2x2_kernel(const u32x4* __restrict__ in, u32x4* __restrict__ out, int B, int H, int W, int vpp) {
+    const size_t total = (size_t)B * H * W * 4 * vpp;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % vpp);
+        size_t r = i / vpp;
+        const int q = (int)(r % 4); r /= 4;
+        const int x = (int)(r % W); r /= W;
+        const int y = (int)(r % H);
+        const int b = (int)(r / H);
+        const int yy = y + (q >> 1), xx = x + (q & 1);
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (yy < H && xx < W) v = in[(((size_t)b * H + yy) * W + xx) * vpp + cv];
+        out[i] = v;
+    }
+}
+extern "C" int advs_gather2x2(const void* in, void* out, int b, int h, int w, int c, int dtype, void* stream) {
+    ADVS_REQUIRE(dtype_ok(dtype), "advs_gather2x2: unknown dtype code %d", dtype);
+    const int vec = dtype == ADVS_F32 ? 4 : 8;
+    ADVS_REQUIRE(in && out && b > 0 && h > 0 && w > 0 && c > 0 && c % vec == 0, "gather2x2: bad args");
+    const size_t total = (size_t)b * h * w * 4 * (c / vec);
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    ADVS_SWITCH_T(dtype, gather2x2_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>((const u32x4*)in, (u32x4*)out, b, h, w, c / vec));
+    ADVS_CHECK_LAUNCH("gather2x2");
+    return ADVS_OK;
+}
+// out[b][2i + (q >> 1)][2j + (q & 1)][:] = y[same] > 0 ? x[b][i][j][q*c .. +c) : 0   (x [b][h/2][w/2][4c], y / out [b][h][w][c])
+template <typename T>
+__global__ void depth_to_space2_relu_kernel(const u32x4* __restrict__ x, const u32x4* __restrict__ y, u32x4* __restrict__ out, int B, int H,
+                                            int W, int vpp) {
+    constexpr int VEC = Elt<T>::VEC;
+    const int Ho = H / 2, Wo = W / 2;
+    const size_t total = (size_t)B * Ho * Wo * 4 * vpp;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % vpp);
+        size_t r = i / vpp;
+        const int q = (int)(r % 4); r /= 4;
+        const int ox = (int)(r % Wo); r /= Wo;
+        const int oy = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        const size_t o = (((size_t)b * H + 2 * oy + (q >> 1)) * W + 2 * ox + (q & 1)) * vpp + cv;
+        float g[VEC], m[VEC];
+        unpack16<T>(x[i], g);
+        unpack16<T>(y[o], m);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) g[e] = m[e] > 0.f ? g[e] : 0.f;
+        out[o] = pack16<T>(g);
+    }
+}
+extern "C" int advs_depth_to_space2_relu(const void* x, const void* y, void* out, int b, int h, int w, int c, int dtype, void* stream) {
+    ADVS_REQUIRE(dtype_ok(dtype), "advs_depth_to_space2_relu: unknown dtype code %d", dtype);
+    const int vec = dtype == ADVS_F32 ? 4 : 8;
+    ADVS_REQUIRE(x && y && out && b > 0 && h > 0 && w > 0 && h % 2 == 0 && w % 2 == 0 && c > 0 && c % vec == 0, "depth_to_space2_relu: bad args");
+    const size_t total = (size_t)b * h * w * (c / vec);
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    ADVS_SWITCH_T(dtype, depth_to_space2_relu_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>((const u32x4*)x, (const u32x4*)y, (u32x4*)out, b, h, w, c / vec));
+    ADVS_CHECK_LAUNCH("depth_to_space2_relu");
+    return ADVS_OK;
+}
+
 // ---------------------------------------------------------------- AdaptiveAvgPool2d(1) backward fused with the last ReLU
 // out[b][p][c] = y[b][p][c] > 0 ? gp[b][c] / HW : 0
 template <typename T>

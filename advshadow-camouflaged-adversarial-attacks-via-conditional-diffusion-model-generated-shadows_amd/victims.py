@@ -130,6 +130,18 @@ class ResNet50(_InputGradient, nn.Module):
             for i in ("1", "2", "3"):
                 w, _ = self._fold(sd, f"{p}.conv{i}", f"{p}.bn{i}")
                 G[f"{p}.w{i}T"] = pack_conv_weight(w.permute(1, 0, 2, 3).flip(2, 3).contiguous(), dt)
+            if s == 2:
+                # the stride-2 3x3 data gradient as one 1x1 GEMM over the gathered output quadruple (csrc/victim_grad.hip): rows =
+                # (input parity p = 2a + b, input channel), columns = (output offset q = 2 di + dj, output channel);
+                # (a, di) -> ky: (0, 0) -> 1, (1, 0) -> 2, (1, 1) -> 0, (0, 1) never meets
+                w2, _ = self._fold(sd, f"{p}.conv2", f"{p}.bn2")                  # [c'][c][3][3]
+                tap = {(0, 0): 1, (1, 0): 2, (1, 1): 0}
+                cw = w2.shape[0]
+                wp = torch.zeros((4, w2.shape[1], 4, cw), dtype=torch.float32, device=w2.device)
+                for (a, di), ky in tap.items():
+                    for (b2, dj), kx in tap.items():
+                        wp[2 * a + b2, :, 2 * di + dj, :] = w2[:, :, ky, kx].t()
+                G[p + ".w2P"] = pack_conv_weight(wp.reshape(4 * w2.shape[1], 4 * cw, 1, 1), dt)
             if ds:
                 w, _ = self._fold(sd, p + ".downsample.0", p + ".downsample.1")
                 G[p + ".wdT"] = pack_conv_weight(w.permute(1, 0, 2, 3).contiguous(), dt)
@@ -277,9 +289,21 @@ class _ResNetGradEngine:
             # the ReLU masks ride the conv epilogues (advs_conv_args.relu_mask) except behind a zero insertion
             for (p, cin, width, cout, s, ds), (hin, y1, y2, y3) in zip(reversed(model.blocks), reversed(acts)):
                 g2 = bld.conv(g, G[p + ".w3T"], width, ksize=1, pad=0, relu_mask=y2)
-                if s == 2:
-                    g2 = zero_insert(g2, y1)
-                g1 = bld.conv(g2, G[p + ".w2T"], width, ksize=3, stride=1, pad=1, relu_mask=y1)
+                if s == 2 and y1.shape[1] % 2 == 0 and y1.shape[2] % 2 == 0:
+                    # parity form: gather the 2x2 output neighbourhood, one 1x1 GEMM for the four input parities, interleave + ReLU mask
+                    gh2, gw2 = g2.shape[1], g2.shape[2]
+                    g4 = bld.buf((batch, gh2, gw2, 4 * width))
+                    plan.add(lib.advs_gather2x2, ptr(g2), ptr(g4), batch, gh2, gw2, width, dt, keep=(g2, g4))
+                    gq = bld.conv(g4, G[p + ".w2P"], 4 * width, ksize=1, pad=0)
+                    bld.free(g4)
+                    g1 = bld.buf(tuple(y1.shape))
+                    plan.add(lib.advs_depth_to_space2_relu, ptr(gq), ptr(y1), ptr(g1), batch, y1.shape[1], y1.shape[2], width, dt,
+                             keep=(gq, y1, g1))
+                    bld.free(gq)
+                else:
+                    if s == 2:
+                        g2 = zero_insert(g2, y1)
+                    g1 = bld.conv(g2, G[p + ".w2T"], width, ksize=3, stride=1, pad=1, relu_mask=y1)
                 bld.free(g2)
                 if ds:
                     res = bld.conv(g, G[p + ".wdT"], cin, ksize=1, pad=0)

@@ -376,6 +376,11 @@ int advs_softmax_ce_grad(const float* logits, const long long* labels, float* ou
 int advs_relu_bwd(const void* g, const void* add, const void* y, void* out, long long n, int dtype, void* stream);
 /* out[b][2i][2j] = in[b][i][j], zero elsewhere; out is [b][ho][wo][c] with ho in {2h-1, 2h} (likewise wo).           */
 int advs_zero_insert2x(const void* in, void* out, int b, int h, int w, int c, int ho, int wo, int dtype, void* stream);
+/* The stride-2 3x3 data gradient without zero insertion (even h, w): out[b][i][j] = [in[i][j] | in[i][j+1] | in[i+1][j] | in[i+1][j+1]]
+ * (zeros beyond the border), then advs_conv2d 1x1 on the host-packed [4c'] -> [4c] parity matrix, then the interleave with the ReLU
+ * mask: out[b][2i + (q>>1)][2j + (q&1)][:] = y > 0 ? x[b][i][j][q*c .. +c) : 0.                                                   */
+int advs_gather2x2(const void* in, void* out, int b, int h, int w, int c, int dtype, void* stream);
+int advs_depth_to_space2_relu(const void* x, const void* y, void* out, int b, int h, int w, int c, int dtype, void* stream);
 /* out[b][p][c] = y[b][p][c] > 0 ? gp[b][c] / hw : 0  (AdaptiveAvgPool2d(1) backward + the last block's ReLU)         */
 int advs_avgpool_bwd_relu(const float* gp, const void* y, void* out, int b, int hw, int c, int dtype, void* stream);
 /* MaxPool2d(3,2,1) backward (first maximum of a window gets its gradient, as torch) times [x > 0]; x [b][h][w][c] is
