@@ -269,7 +269,9 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvKP& p, f32x16 (&acc
             const int row = it * RPI + prow;
             const int m = row_to_m(i * 32 + row);
             const u32x4 v = *(const u32x4*)(patch + row * ROWB + pcv * 16);
-            if (m >= 0 && n_ok) *(u32x4*)(y + ((size_t)m * p.Cout + n) * 2) = v;
+            // y is read next by a GroupNorm pass over a tensor far larger than the L2: streaming it past the caches leaves them to the
+            // halo and weight re-reads (conv -1.5 %, round 2; the generic epilogue keeps plain stores: the victims' small maps want the L2)
+            if (m >= 0 && n_ok) __builtin_nontemporal_store(v, (u32x4*)(y + ((size_t)m * p.Cout + n) * 2));
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
