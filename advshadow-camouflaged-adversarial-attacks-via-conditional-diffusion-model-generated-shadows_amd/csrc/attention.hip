@@ -528,7 +528,11 @@ static int attn_launch_dt(const AttnP& p, hipStream_t st) {
 template <typename T>
 static int attn_launch(const AttnP& p, hipStream_t st) {
     if constexpr (sizeof(T) == 2) {
-        static const bool old_kernel = getenv("ADVS_ATTN_V1") != nullptr;      // A/B knob for tools/
+#ifdef ADVS_DIAG
+        static const bool old_kernel = getenv("ADVS_ATTN_V1") != nullptr;      // A/B knob for tools/ (diagnostic builds only)
+#else
+        constexpr bool old_kernel = false;
+#endif
         if (!p.bias && p.d <= 64 && !old_kernel) {
             if (p.d <= 32) return attn2_launch<T, 1, 4>(p, st);
             return attn2_launch<T, 2, 2>(p, st);

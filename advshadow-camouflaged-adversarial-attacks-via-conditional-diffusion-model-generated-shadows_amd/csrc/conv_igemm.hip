@@ -313,11 +313,21 @@ static int conv_launch(ConvKP& p, hipStream_t st) {
 static int pick_tile(long long m_img, int cout);
 bool conv_halo_eligible(const ConvKP& p);
 int conv_halo_dispatch(ConvKP& p, int dtype, hipStream_t st);
-bool conv_halo512_eligible(const ConvKP& p, int dtype);
-int conv_halo512_dispatch(ConvKP& p, int dtype, hipStream_t st);
 int conv_halo_subpixel_dispatch(ConvKP& p, int dtype, hipStream_t st);
 bool conv_halo_extra_eligible(const ConvKP& p);
 int conv_halo_extra_dispatch(ConvKP& p, int dtype, hipStream_t st);
+bool conv_halo2_eligible(const ConvKP& p, int dtype, int tile, int kind);
+int conv_halo2_dispatch(ConvKP& p, int dtype, int tile, int kind, hipStream_t st);
+
+// A/B knobs read from the environment exist only in diagnostic builds (make DIAG=1, used by tools/); the shipped library's
+// dispatch depends on the call's arguments alone.
+#ifdef ADVS_DIAG
+#define ADVS_DIAG_ENV(name) (getenv(name) != nullptr)
+#define ADVS_DIAG_ENV_LL(name, dflt) (getenv(name) ? atoll(getenv(name)) : (long long)(dflt))
+#else
+#define ADVS_DIAG_ENV(name) false
+#define ADVS_DIAG_ENV_LL(name, dflt) ((long long)(dflt))
+#endif
 
 template <typename T>
 static int conv_dispatch(ConvKP& p, int tile, hipStream_t st) {
@@ -361,27 +371,41 @@ static int pick_tile(long long m_img, int cout) {
     // Small maps (the victims' 56x56 .. 7x7 layers, the ViTs' token rows): 64-row tiles in 4-wave workgroups -- three to a CU, and a
     // launch of a few thousand rows still has work for every CU.  ResNet-50 attack at batch 32: 396 -> 490 images/s, ViT-B 229 -> 233,
     // VGG16 and the eps-predictor unchanged (tools/_diag sweep, round 2).  64 x 64 tiles below 15 x 15 pixels only: ViT's wide GEMMs
-    // (208 rows per image, 768-3072 columns) lose 9 % on them.  The environment variables are tuning knobs.
-    static const long long t15_m = getenv("ADVS_T15_M") ? atoll(getenv("ADVS_T15_M")) : 3136;
-    static const long long t16_m = getenv("ADVS_T16_M") ? atoll(getenv("ADVS_T16_M")) : 196;
+    // (208 rows per image, 768-3072 columns) lose 9 % on them.  (Diagnostic builds read the two thresholds from the environment.)
+    static const long long t15_m = ADVS_DIAG_ENV_LL("ADVS_T15_M", 3136);
+    static const long long t16_m = ADVS_DIAG_ENV_LL("ADVS_T16_M", 196);
     if (m_img <= t16_m) return 16;
     if (m_img <= t15_m) return 15;
     return (cout % 256 == 0 && blocks256 >= 12) ? 4 : 1;
 }
 // the 16x16-pixel halo kernel wins wherever it applies (3x3, stride 1, no upsample / extra operand, image a
 // multiple of 16: +15..30 % over the per-tap tiles on every such layer of the eps-predictor, tools/tune_conv.py)
+// tiles 17-19 (conv_halo2.hip) by the descriptor alone: 16-bit, 3x3 stride 1 pad 1, plain or sub-pixel upsample, optional fused 1x1
+static bool halo2_args_ok(const advs_conv_args* a, int tile) {
+    if (tile < 17 || tile > 19 || a->dtype == ADVS_F32 || a->relu_mask) return false;
+    if (!(a->ksize == 3 && a->stride == 1 && a->pad == 1 && a->h % 16 == 0 && a->w_ % (tile == 17 ? 32 : 16) == 0)) return false;
+    if ((long long)a->b * a->h * a->w_ >= (1ll << 28)) return false;
+    if (a->upsample == ADVS_UPSAMPLE_SUBPIXEL) return !a->e1;
+    return !a->upsample;
+}
 static int resolve_tile(const advs_conv_args* a, long long m_img) {
-    if (a->upsample == ADVS_UPSAMPLE_SUBPIXEL) return 12;       // weights are packed per output parity: one kernel only
+    const int want = g_tile_override ? g_tile_override : a->tile;
+    if (halo2_args_ok(a, want)) return want;
+    // Second-generation halo kernels wherever they apply (16-bit, 3x3 stride 1; plain, sub-pixel upsample or fused 1x1 operand).  Measured
+    // round 3 (tools/conv_one.py --suite, profiles/round3_halo2.txt): from 128 x 128 maps up the 4-wave form with two workgroups per CU
+    // (tile 19) is 4-18 % faster than tile 10 on every layer shape of the eps-predictor, at 64 x 64 the 16 x 32-pixel form (tile 17) by
+    // 2-7 %; at 32 x 32 tile 10's 256 workgroups of 8 waves stay ahead.  The rule looks at ONE image's map, never at the batch.
+    if (!want && halo2_args_ok(a, 19)) {
+        const long long hw = (long long)a->h * a->w_;
+        if (hw >= 128 * 128) return 19;
+        if (hw >= 64 * 64) return a->w_ % 32 == 0 ? 17 : 19;
+    }
+    if (a->upsample == ADVS_UPSAMPLE_SUBPIXEL) return 12;       // weights are packed per output parity: the halo kernels only
     if (a->relu_mask) return a->tile ? a->tile : pick_tile(m_img, a->cout);
     if (g_tile_override) return g_tile_override;
     if (a->tile) return a->tile;
     // (with a fused 1x1 operand tile 10 becomes 13: the same kernel with one-tap units behind the 3x3 slabs, +3 %)
-    static const bool no_halo_extra = getenv("ADVS_NO_HALO_EXTRA") != nullptr;      // A/B knob for tools/
-    // 14: the 512-pixel halo kernel (conv_halo512.hip), from 128 x 128 images up (a rule on ONE image's size, see pick_tile)
-    static const bool halo512 = getenv("ADVS_HALO512") != nullptr;
-    if (halo512 && a->dtype != ADVS_F32 && a->ksize == 3 && a->stride == 1 && a->pad == 1 && !a->upsample && !a->e1 && a->h % 16 == 0 &&
-        a->w_ % 32 == 0 && m_img >= 128 * 128)
-        return 14;
+    const bool no_halo_extra = ADVS_DIAG_ENV("ADVS_NO_HALO_EXTRA");
     if (a->ksize == 3 && a->stride == 1 && a->pad == 1 && !a->upsample && (!a->e1 || !no_halo_extra) && a->h % 16 == 0 && a->w_ % 16 == 0)
         return 10;
     return pick_tile(m_img, a->cout);
@@ -395,7 +419,12 @@ extern "C" int advs_conv_resolve_tile(const advs_conv_args* a) {
     return resolve_tile(a, ho * wo);
 }
 extern "C" int advs_conv_tile_rows(int tile) {
-    switch (tile) { case 1: case 2: case 5: case 6: case 8: case 10: case 12: case 13: return 64; case 3: case 4: case 7: case 9: case 14: return 128; case 15: case 16: return 32; default: return 0; }
+    switch (tile) {
+        case 1: case 2: case 5: case 6: case 8: case 10: case 12: case 13: case 17: case 18: case 19: return 64;
+        case 3: case 4: case 7: case 9: return 128;
+        case 15: case 16: return 32;
+        default: return 0;
+    }
 }
 
 extern "C" int advs_conv2d(const advs_conv_args* a, void* stream) {
@@ -453,12 +482,12 @@ extern "C" int advs_conv2d(const advs_conv_args* a, void* stream) {
     p.act = a->act; p.temb_stride = a->temb_stride > 0 ? a->temb_stride : a->cout;
     p.dHoWo.init((unsigned)(p.Ho * p.Wo)); p.dWo.init((unsigned)p.Wo);
     int tile = resolve_tile(a, (long long)p.Ho * p.Wo);
-    if (tile == 10 && conv_halo_extra_eligible(p)) tile = 13;   // 13: the halo kernel with the fused 1x1 operand
-    if (tile == 14 && !conv_halo512_eligible(p, a->dtype)) {
-        ADVS_REQUIRE(g_tile_override != 0, "conv2d: tile 14 (512-pixel halo kernel) needs a 16-bit dtype, 3x3 stride 1 pad 1, no upsample / extra operand, H a multiple of 16 and W of 32");
-        tile = 10;                                           // tuning override on a shape it cannot take
-        if (conv_halo_extra_eligible(p)) tile = 13;
+    const int h2kind = subpixel ? 1 : (p.e1 ? 2 : 0);
+    if (tile >= 17 && tile <= 19 && !conv_halo2_eligible(p, a->dtype, tile, h2kind)) {
+        ADVS_REQUIRE(g_tile_override != 0, "conv2d: tile %d (second-generation halo kernel) cannot take this shape", tile);
+        tile = subpixel ? 12 : 10;                           // tuning override on a shape it cannot take
     }
+    if (tile == 10 && conv_halo_extra_eligible(p)) tile = 13;   // 13: the halo kernel with the fused 1x1 operand
     if (tile == 10 && !conv_halo_eligible(p)) {
         ADVS_REQUIRE(g_tile_override != 0, "conv2d: tile 10 (halo kernel) needs 3x3 stride 1 pad 1, no upsample / extra operand, H and W multiples of 16");
         tile = pick_tile((long long)p.Ho * p.Wo, a->cout);   // tuning override on a shape the halo kernel cannot take
@@ -471,12 +500,12 @@ extern "C" int advs_conv2d(const advs_conv_args* a, void* stream) {
         else ADVS_REQUIRE(a->stats_rows == wm, "conv2d: stats buffer sized for %d-row blocks but the tile uses %d", a->stats_rows, wm);
     }
     // the halo kernels' fast epilogue (conv_common.h): 16-bit storage, nothing but bias / time embedding / statistics around the GEMM
-    p.fast_epi = (tile == 10 || tile == 12 || tile == 13 || tile == 14) && a->dtype != ADVS_F32 && !a->residual && !a->relu_mask &&
-                 a->act == ADVS_ACT_NONE && getenv("ADVS_NO_FAST_EPILOGUE") == nullptr;
+    p.fast_epi = (tile == 10 || tile == 12 || tile == 13 || (tile >= 17 && tile <= 19)) && a->dtype != ADVS_F32 && !a->residual && !a->relu_mask &&
+                 a->act == ADVS_ACT_NONE && !ADVS_DIAG_ENV("ADVS_NO_FAST_EPILOGUE");
+    if (tile >= 17 && tile <= 19) return conv_halo2_dispatch(p, a->dtype, tile, h2kind, (hipStream_t)stream);
     if (tile == 12) return conv_halo_subpixel_dispatch(p, a->dtype, (hipStream_t)stream);
     if (tile == 13) return conv_halo_extra_dispatch(p, a->dtype, (hipStream_t)stream);
     if (tile == 10) return conv_halo_dispatch(p, a->dtype, (hipStream_t)stream);
-    if (tile == 14) return conv_halo512_dispatch(p, a->dtype, (hipStream_t)stream);
     ADVS_SWITCH_T(a->dtype, return conv_dispatch<T>(p, tile, (hipStream_t)stream));
     return ADVS_ERR_ARG;                    // not reached
 }

@@ -372,7 +372,11 @@ static int attention_bwd_impl(const void* qkv, const void* out, const void* d_ou
     ADVS_REQUIRE(dtype_ok(dtype), "advs_attention_bwd: unknown dtype code %d", dtype);
     ADVS_REQUIRE(qkv && out && d_out && d_qkv && scratch && b > 0 && n > 0 && n_valid > 0 && n_valid <= n && heads > 0, "attention_bwd: bad args");
     ADVS_REQUIRE(d > 0 && d <= 64, "attention_bwd: d=%d must be in 1..64", d);
-    static const bool valu_only = getenv("ADVS_ATTN_BWD_V1") != nullptr;          // A/B knob for tools/
+#ifdef ADVS_DIAG
+    static const bool valu_only = getenv("ADVS_ATTN_BWD_V1") != nullptr;          // A/B knob for tools/ (diagnostic builds only)
+#else
+    constexpr bool valu_only = false;
+#endif
     if (dtype != ADVS_F32 && !valu_only && d % 8 == 0 && ld % 8 == 0 && q_off % 8 == 0 && k_off % 8 == 0 && v_off % 8 == 0 &&
         head_stride % 8 == 0)
         return attn_bwd_mfma(qkv, out, d_out, d_qkv, scratch, b, n, n_valid, heads, d, ld, q_off, k_off, v_off, head_stride, dtype,

@@ -43,18 +43,25 @@ CONV_CASES = [
     (3, 16, 32, 64, 0, 64, 3, 1, 0, 0, 1, 0, None),        # halo-eligible: batch 3, N tail (64 < 128), 1 slab
     (2, 16, 32, 64, 128, 128, 3, 1, 0, 1, 1, 1, None),     # 512-pixel halo tile: concat (2 + 4 half slabs), full epilogue
     (1, 32, 64, 128, 0, 128, 3, 1, 0, 1, 1, 0, None),      # 512-pixel halo tile: 2x2 pixel tiles, the fast epilogue's shape
+    (2, 32, 32, 64, 0, 192, 3, 1, 0, 1, 0, 0, None),       # second-generation halo tiles: one unit pair, N tail (192), statistics-free fast epilogue
 ]
 
+HALO2_TILES = (17, 18, 19)          # conv_halo2.hip: 16 x 32 pixels / 8 waves, 16 x 16 / 8 waves, 16 x 16 / 4 waves
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 14, 15, 16])
+
+def halo2_ok(tile, dt, H, W):
+    return dt != "fp32" and H % 16 == 0 and W % (32 if tile == 17 else 16) == 0
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 15, 16, 17, 18, 19])
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv2d(case, dt, tile):
     B, H, W, C1, C2, Cout, k, stride, ups, has_b, has_t, has_r, act = case
     if tile == 10 and not (k == 3 and stride == 1 and not ups and H % 16 == 0 and W % 16 == 0):
         pytest.skip("halo kernel: 3x3 stride 1, H and W multiples of 16")
-    if tile == 14 and not (k == 3 and stride == 1 and not ups and H % 16 == 0 and W % 32 == 0 and dt != "fp32"):
-        pytest.skip("512-pixel halo kernel: 16-bit, 3x3 stride 1, H a multiple of 16, W of 32")
+    if tile in HALO2_TILES and not (k == 3 and stride == 1 and not ups and halo2_ok(tile, dt, H, W)):
+        pytest.skip("second-generation halo kernels: 16-bit, 3x3 stride 1, H a multiple of 16, W of 16 (tile 17: 32)")
     pad = 1 if k == 3 else 0
     x1 = rnd(B, C1, H, W, seed=1)
     x2 = rnd(B, C2, H, W, seed=2) if C2 else None
@@ -395,13 +402,13 @@ def test_groupnorm_chan_add(dt):
 
 # ------------------------------------------------------------------------------ GN statistics from the conv epilogue
 @pytest.mark.parametrize("dt", DTS)
-@pytest.mark.parametrize("tiles", [(1, 1), (4, 1), (1, 4), (3, 5), (10, 1), (14, 1)])
+@pytest.mark.parametrize("tiles", [(1, 1), (4, 1), (1, 4), (3, 5), (10, 1), (17, 1), (18, 1), (19, 1)])
 def test_groupnorm_with_epilogue_stats(dt, tiles):
     """conv(+stats) x2 -> GroupNorm(32) over their concat (groups of 12 straddle the sources) must equal
     the unfused path; statistics come from [row block][channel] partials written by the epilogues."""
-    if tiles[0] == 14 and dt == "fp32":
-        pytest.skip("512-pixel halo kernel: 16-bit only")
-    B, H, W = 2, 16, 32 if tiles[0] == 14 else 16
+    if tiles[0] in HALO2_TILES and dt == "fp32":
+        pytest.skip("second-generation halo kernels: 16-bit only")
+    B, H, W = 2, 16, 32 if tiles[0] == 17 else 16
     xa, xb = rnd(B, 64, H, W, seed=41), rnd(B, 64, H, W, seed=42)
     wa, wb = rnd(256, 64, 3, 3, seed=43, scale=0.05), rnd(128, 64, 1, 1, seed=44, scale=0.2)
     gamma, beta = rnd(384, seed=45) * 0.3 + 1, rnd(384, seed=46) * 0.1
@@ -451,11 +458,15 @@ def test_conv2d_with_extra_1x1_operand(dt, tile, two):
     # B, H, W, Ca (one or two sources), Cout, E1, E2, residual-free full epilogue with temb + stats
     (2, 16, 16, (128, 0), 128, 64, 0), (1, 32, 16, (128, 0), 128, 256, 128), (2, 16, 16, (64, 64), 256, 128, 128),
     (1, 16, 48, (64, 0), 64, 64, 64), (3, 16, 16, (128, 0), 128, 192, 0),
+    (1, 16, 32, (64, 64), 128, 128, 64), (2, 32, 64, (128, 0), 256, 64, 0),      # widths the 16 x 32-pixel tile takes
 ])
-def test_conv2d_extra_operand_on_the_halo_kernel(case, dt):
-    """The fused shortcut operand as one-tap units behind the 3x3 slabs of the halo kernel (tile 10 -> 13): one to six
-    extra slabs, e1 only and e1 + e2, two 3x3 sources, temb and epilogue statistics."""
+@pytest.mark.parametrize("tile", [10, 17, 18, 19])
+def test_conv2d_extra_operand_on_the_halo_kernel(case, dt, tile):
+    """The fused shortcut operand as one-tap units behind the 3x3 slabs of the halo kernels (tile 10 -> 13, and tiles 17-19): one
+    to six extra slabs, e1 only and e1 + e2, two 3x3 sources, temb and epilogue statistics."""
     B, H, W, (C1, C2), Cout, E1, E2 = case
+    if tile in HALO2_TILES and not halo2_ok(tile, dt, H, W):
+        pytest.skip("second-generation halo kernels: 16-bit, W a multiple of 32 for tile 17")
     x1 = rnd(B, C1, H, W, seed=111)
     x2 = rnd(B, C2, H, W, seed=112) if C2 else None
     e1 = rnd(B, E1, H, W, seed=113)
@@ -472,7 +483,7 @@ def test_conv2d_extra_operand_on_the_halo_kernel(case, dt):
                       pack_conv_weight(w1.to(dev()), code).reshape(Cout, -1)], 1).contiguous()
     op = OneOp(dt, B)
     y = op.b.conv(nhwc(x1, dt), wcat, Cout, x2=nhwc(x2, dt) if C2 else None, bias=bias.to(dev()), temb=temb.to(dev()),
-                  temb_stride=Cout, extra=(nhwc(e1, dt), nhwc(e2, dt) if E2 else None), tile=10, want_stats=True)
+                  temb_stride=Cout, extra=(nhwc(e1, dt), nhwc(e2, dt) if E2 else None), tile=tile, want_stats=True)
     assert y.data_ptr() in op.b.stats
     g, be = rnd(Cout, seed=119) + 1, rnd(Cout, seed=120)
     n = op.b.groupnorm(y, g.to(dev()), be.to(dev()), 32, act="silu")
@@ -588,10 +599,14 @@ def test_groupnorm_with_epilogue_stats_narrow_channels(dt):
     # B, H, W, C1, C2, Cout, bias, temb, res, act, stats
     (1, 16, 16, 64, 0, 128, 1, 0, 0, None, 0), (2, 32, 16, 128, 0, 256, 1, 1, 1, "silu", 1), (1, 16, 48, 64, 64, 64, 0, 0, 0, None, 1),
     (3, 16, 16, 256, 0, 256, 1, 0, 0, None, 0),
+    (1, 16, 32, 64, 0, 128, 1, 1, 0, None, 1), (2, 16, 64, 128, 64, 256, 1, 0, 1, None, 0),      # widths the 16 x 32-pixel tile takes
 ])
-def test_conv2d_upsample_subpixel(case, dt):
+@pytest.mark.parametrize("tile", [0, 17, 18, 19])
+def test_conv2d_upsample_subpixel(case, dt, tile):
     """nearest x2 + 3x3 (Upsample, diff_model.py:129-140) as four 2x2 convolutions of the low-res input."""
     B, H, W, C1, C2, Cout, has_b, has_t, has_r, act, stats = case
+    if tile in HALO2_TILES and not halo2_ok(tile, dt, H, W):
+        pytest.skip("second-generation halo kernels: 16-bit, W a multiple of 32 for tile 17")
     x1 = rnd(B, C1, H, W, seed=101)
     x2 = rnd(B, C2, H, W, seed=102) if C2 else None
     w = rnd(Cout, C1 + C2, 3, 3, seed=103, scale=1.0 / math.sqrt((C1 + C2) * 9))
@@ -612,7 +627,7 @@ def test_conv2d_upsample_subpixel(case, dt):
     assert w4.shape == (4, Cout, 2, 2, C1 + C2)
     y = op.b.conv(nhwc(x1, dt), w4, Cout, x2=nhwc(x2, dt) if C2 else None, bias=bias.to(dev()) if has_b else None,
                   temb=temb.to(dev()) if has_t else None, temb_stride=Cout if has_t else 0,
-                  residual=nhwc(res, dt) if has_r else None, upsample="subpixel", act=act, want_stats=bool(stats))
+                  residual=nhwc(res, dt) if has_r else None, upsample="subpixel", act=act, want_stats=bool(stats), tile=tile)
     n = None
     if stats:
         assert y.data_ptr() in op.b.stats

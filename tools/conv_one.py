@@ -96,8 +96,6 @@ def main():
         return
     tot = 0.0
     for h, c1, cout, extra, temb, res, ups in SUITE:
-        if a.tile == 14 and (extra or ups):
-            continue                                   # the 512-pixel halo kernel takes the plain 3x3 convs only
         ms, fl = one(a, h, c1, cout, extra, temb, res, ups, quiet=True)
         tot += ms
         print(f"h {h:3d} c1 {c1:3d} cout {cout:3d} extra {extra:3d} temb {temb} res {res} ups {ups}: {ms * 1e3:7.0f} us  {fl / ms / 1e9:6.0f} TF (algorithmic)")
