@@ -23,7 +23,7 @@ class ConvArgs(C.Structure):
                 ("b", i32), ("h", i32), ("w_", i32), ("c1", i32), ("c2", i32), ("cout", i32),
                 ("ksize", i32), ("stride", i32), ("pad", i32), ("upsample", i32),
                 ("act", i32), ("dtype", i32), ("temb_stride", i32), ("tile", i32), ("stats", vp), ("stats_rows", i32), ("e1", vp), ("e2", vp), ("ce1", i32), ("ce2", i32),
-                ("ld1", i32), ("ld2", i32), ("relu_mask", vp)]
+                ("ld1", i32), ("ld2", i32), ("relu_mask", vp), ("norm", vp)]
 
 
 # name -> argtypes (restype is int unless listed in _RESTYPES)
@@ -38,6 +38,7 @@ SIGNATURES = {
     "advs_conv_resolve_tile": [C.POINTER(ConvArgs)],
     "advs_conv_tile_rows": [i32],
     "advs_groupnorm_stats": [vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    "advs_groupnorm_affine_stats": [vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "advs_conv3x3_first": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "advs_conv3x3_first_stats": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "advs_conv_first_stats_rows": [i32, i32, i32, i32, i32],

@@ -21,6 +21,7 @@ struct ConvKP {
     const char* e1; const char* e2;   // extra 1x1 operand (two concat sources) appended to K, or null
     int E1, E2; unsigned e1_bytes, e2_bytes;
     const float* bias; const float* temb; const char* res; char* y;
+    const float* norm;           // [B][C1 + C2][2] (scale, shift): the conv reads SiLU(scale * x + shift) (advs_conv_args.norm), or null
     const char* mask;            // ReLU-backward mask (advs_conv_args.relu_mask), read only by the MASK instantiations
     float* stats;                // [ceil(M/WM)][Cout][2] per-channel (sum, sum of squares) of y, or null
     unsigned x1_bytes, x2_bytes, w_bytes;

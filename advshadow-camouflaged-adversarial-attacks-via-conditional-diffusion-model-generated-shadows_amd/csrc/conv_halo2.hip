@@ -51,6 +51,8 @@ struct H2Geom {
     static constexpr int LDS_MAIN = 2 * A_STAGE + NB * B_STAGE;
     static constexpr int LDS_EPI = NW * 32 * WNC * 4;          // generic epilogue: one f32 patch per wave
     static constexpr int LDS = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
+    static constexpr int NORM_MAXC = 384;                      // input channels of the GroupNorm-on-load form: an 8-byte (scale, shift) each
+    static constexpr int LDS_NORM = LDS_MAIN + NORM_MAXC * 8 > LDS_EPI ? LDS_MAIN + NORM_MAXC * 8 : LDS_EPI;
     static_assert(B_STAGE / 1024 % NW == 0 && NBP >= 1, "whole weight pieces per wave");
     static_assert(TM * WM * 32 == TY * TX && TM >= 1, "pixel tiles divide over the waves");
     static_assert(NAP <= 6, "the halo pieces of a unit ride one per tap in taps 0..5");
@@ -81,9 +83,22 @@ template <int NT, int NAP> __host__ __device__ constexpr int h2_a_first(int t) {
 
 // NT = 9: 3x3.  NT = 4: sub-pixel form of nearest-x2 + 3x3 (weights [parity][Cout][2x2][Cin], conv_halo.hip).
 // XT: fused 1x1 operand (ResidualBlock.shortcut) as one-tap units behind the 3x3 units.
-template <typename T, typename G, int NT, bool XT>
+// NORM: GroupNorm + SiLU of the 3x3 input applied in LDS (advs_conv_args.norm; norm_layer + SiLU + Conv2d, diff_model.py:70-73,
+// 83-86).  The wave that DMA'd a halo piece transforms it two taps later (its own vmcnt covers its own piece): every lane reads
+// back the 16 bytes it fetched, y = silu_fast(fma(x, scale_c, shift_c)) -- gn_apply_kernel's arithmetic, rounded to T the same
+// way, so the MFMA sees the bits the two-pass form would have stored -- and writes them in place; lanes whose slot is zero
+// padding (outside the image) leave the zeros.  The next unit's pieces ride in taps 0-5 and are transformed in taps 2-7; the
+// barrier that opens the last tap publishes them before its closing prefetch reads the next halo.  ~76 VALU issue slots per 8
+// elements, once per element per workgroup (plus the halo ring) -- against a separate pass that reads and writes the tensor
+// through HBM.  Measured (round 3, level-0 layers, batch 32): +0.10-0.12 ms per 128 input channels on the conv against 0.19 ms
+// for the pass it replaces; the cost equals the transform's VALU issue time, and a sched_group_barrier ladder that spreads it
+// between the MFMAs changes nothing (20.86 vs 20.74 ms of conv per forward) -- it is issue / power, not placement.  With two
+// 128-channel output tiles the transform would run twice per element and lose: the host fuses single-tile layers only.
+// The (scale, shift) rows of the image sit in LDS behind the weight ring.
+template <typename T, typename G, int NT, bool XT, bool NORM = false>
 __global__ void __launch_bounds__(G::NTHR, G::MINW)
 conv3x3_halo2_kernel(const ConvKP p) {
+    static_assert(!NORM || NT == 9, "the normalising form is the 3x3 kernel's");
     static_assert(sizeof(T) == 2, "16-bit dtypes only");
     static_assert(!XT || NT == 9, "the extra operand is only wired into the 3x3 kernel");
     constexpr int TM = G::TM, TN = G::TN, KS = G::KS, NAP = G::NAP, NBP = G::NBP, NW = G::NW, KC = G::KC;
@@ -92,6 +107,7 @@ conv3x3_halo2_kernel(const ConvKP p) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];   // [2][A_STAGE] then [NB][B_STAGE]
     char* sA = smem;
     char* sB = smem + 2 * G::A_STAGE;
+    char* sN = smem + G::LDS_MAIN;                                  // NORM: [Cin][2] f32 (scale, shift) of this image
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -174,6 +190,34 @@ conv3x3_halo2_kernel(const ConvKP p) {
         issue_Bg(g3, (unsigned)(t3 * Cin + u3 * KC) * 2u, j);
     };
 
+    // NORM: half h (8 of the lane's 16 bytes = four channels) of piece j of `unit`'s halo -- this wave's own DMA, already waited
+    // for -- becomes SiLU(scale * x + shift) in place.  Branch-free, so that a tap stays one scheduling region: a lane on zero
+    // padding (outside the image) writes its zeros back, a padding piece (q >= A_PIECES) works on the scratch piece.
+    auto norm_half = [&](int unit, int j, int h, bool on) {
+        const int q = wave + NW * j;
+        char* slot = sA + (unit & 1) * G::A_STAGE + (q < G::A_PIECES ? q : G::A_PIECES) * 1024 + lane * 16 + h * 8;
+        const u32x2 raw = *(const u32x2*)slot;
+        const float* co = (const float*)(sN + (unit * KC + (int)(a_pk[j] & (G::NCH - 1)) * 8 + h * 4) * 8);
+        const f32x4 c0 = *(const f32x4*)co, c1 = *(const f32x4*)(co + 4);
+        float f[4];
+        if constexpr (std::is_same<T, BF16>::value) {
+            f[0] = __uint_as_float(raw[0] << 16); f[1] = __uint_as_float(raw[0] & 0xffff0000u);
+            f[2] = __uint_as_float(raw[1] << 16); f[3] = __uint_as_float(raw[1] & 0xffff0000u);
+        } else {
+            f[0] = f16_to_f32((unsigned short)(raw[0] & 0xffffu)); f[1] = f16_to_f32((unsigned short)(raw[0] >> 16));
+            f[2] = f16_to_f32((unsigned short)(raw[1] & 0xffffu)); f[3] = f16_to_f32((unsigned short)(raw[1] >> 16));
+        }
+        f[0] = silu_fast(fmaf(f[0], c0[0], c0[1]));
+        f[1] = silu_fast(fmaf(f[1], c0[2], c0[3]));
+        f[2] = silu_fast(fmaf(f[2], c1[0], c1[1]));
+        f[3] = silu_fast(fmaf(f[3], c1[2], c1[3]));
+        const bool live = on && a_pk[j] != 0xFFFFFFFFu;       // (`on` false: the next unit is not a 3x3 unit -- its bytes go back unchanged)
+        u32x2 out;
+        out[0] = live ? pack2<T>(f[0], f[1]) : raw[0];
+        out[1] = live ? pack2<T>(f[2], f[3]) : raw[1];
+        *(u32x2*)slot = out;
+    };
+
     // ---- fragment geometry: wave (wm, wn) owns MFMA pixel tiles wm*TM .. +TM-1 (two 16-pixel strips each) and channels wn*WNC ..
     // a_addr[i][s][ks]: byte address inside the halo image of tile i's fragment at column shift s0 + s, k-step ks, row shift 0
     unsigned a_addr[TM][NTW][KS], b_addr[TN][KS];
@@ -224,6 +268,16 @@ conv3x3_halo2_kernel(const ConvKP p) {
                 else issue_Bg(g, (unsigned)((g % NT) * Cin + (g / NT) * KC) * 2u, j);
             }
 
+    if constexpr (NORM) {
+        // the image's (scale, shift) rows -> LDS, then unit 0's halo pieces (issued ahead of the three weight stages) are transformed
+        const float2* tb = (const float2*)p.norm + (size_t)b * Cin;
+        for (int c = tid; c < Cin; c += G::NTHR) ((float2*)sN)[c] = tb[c];
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NBP) : "memory");
+        __syncthreads();                                             // the table is visible (the weight DMAs drain here too: once per workgroup)
+#pragma unroll
+        for (int j = 0; j < NAP; ++j) { norm_half(0, j, 0, true); norm_half(0, j, 1, true); }
+    }
+
     f32x16 acc[TM][TN];                              // zero, or (fast epilogue) bias + time embedding
     conv_acc_init<TM, TN>(p, acc, lane, n0 + wn * G::WNC, b);
 
@@ -242,17 +296,25 @@ conv3x3_halo2_kernel(const ConvKP p) {
             for (int j = 0; j < TN; ++j) Mma<T>::run(af[cur][i], bf[cur][j], acc[i][j]);
     };
 
+    // the very first fragments: nothing was carried into tap 0 of unit 0 (its own wait + barrier follow; once per workgroup)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NBP) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    load_frags(0, sA, sB, 0, 0, 0);
+
     for (int unit = 0; unit < nunits; ++unit) {
         const bool hn = unit + 1 < nunits + ne;      // a next unit exists: its halo is prefetched during this one
         if (hn && (unit + 1 == ncs1 || unit == 0 || unit + 1 == nunits || unit + 1 == nunits + ne1)) set_a_voff(unit + 1);
         const char* la = sA + (unit & 1) * G::A_STAGE;
         const char* la_next = sA + ((unit + 1) & 1) * G::A_STAGE;
+        const bool norm_on = NORM && unit + 1 < nunits;          // the next unit is a 3x3 unit: its halo is normalised in this one
         auto tap = [&](auto tc) {
             constexpr int t = decltype(tc)::value;
             const int it = unit * NT + t;
             // Outstanding, oldest first: W(t+1) [+halo pieces of tap t-2], W(t+2) [+halo pieces of tap t-1].  Wait for W(t+1).
             // The last tap of a unit reads the NEXT unit's halo at its end: everything but W(t+2) must be in.
-            constexpr int nA = t == NT - 1 ? 0 : h2_a_pieces<NT, NAP>(t - 2) + h2_a_pieces<NT, NAP>(t - 1);
+            // (NORM: the piece of tap t-2 is transformed in this tap, so it must be in as well)
+            constexpr int nA = t == NT - 1 ? 0 : (NORM ? 0 : h2_a_pieces<NT, NAP>(t - 2)) + h2_a_pieces<NT, NAP>(t - 1);
             static_assert(h2_a_pieces<NT, NAP>(NT - 2) == 0, "no halo piece may be issued behind W(t+2) of the last tap");
             if (it + 2 >= gtaps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // no W(t+2): nothing may be pending
             else if (hn) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBP + nA) : "memory");
@@ -262,10 +324,12 @@ conv3x3_halo2_kernel(const ConvKP p) {
             constexpr int r = t / NTW, s = t % NTW;                   // tap shift relative to (r0, s0), which a_addr carries
             const char* lb = sB + (it & (G::NB - 1)) * G::B_STAGE;
             const char* lbn = sB + ((it + 1) & (G::NB - 1)) * G::B_STAGE;
-            if (it == 0) load_frags(0, la, lb, r, s, 0);              // nothing was carried into the very first tap
-            // this tap's DMA issues, weights first (the counted wait assumes that order), spread towards the late k-steps
+            // this tap's DMA issues, weights first (the counted wait assumes that order), spread towards the late k-steps; they open
+            // their k-step, so that what follows (fragment reads, NORM arithmetic, MFMAs) is ONE scheduling region per k-step
             constexpr int nAt = h2_a_pieces<NT, NAP>(t), a0 = h2_a_first<NT, NAP>(t);
             constexpr int nops = NBP + nAt;
+            // NORM: this tap transforms the piece the wave issued two taps ago, half of it beside each of the first two k-steps' MFMAs
+            constexpr bool norm_here = NORM && t >= 2 && h2_a_pieces<NT, NAP>(t - 2) > 0;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const int cur = ks & 1, nxt = cur ^ 1;
@@ -284,6 +348,9 @@ conv3x3_halo2_kernel(const ConvKP p) {
                 } else if (hn) {                                      // ... or the first tap of the next unit's halo
                     if (XT && unit + 1 >= nunits) load_frags(nxt, la_next, lbn, 1, 1, 0);   // an extra unit's only tap: the centre
                     else load_frags(nxt, la_next, lbn, 0, 0, 0);
+                }
+                if constexpr (norm_here) {
+                    if (ks < 2) norm_half(unit + 1, t - 2, ks, norm_on);
                 }
                 mma_step(cur);
             }
@@ -356,16 +423,17 @@ bool conv_halo2_eligible(const ConvKP& p, int dtype, int tile, int kind) {
     return kind == 2 ? p.e1 != nullptr : p.e1 == nullptr;
 }
 
-template <typename T, typename G, int NT, bool XT>
+template <typename T, typename G, int NT, bool XT, bool NORM = false>
 static int h2_launch(ConvKP& p, hipStream_t st) {
+    constexpr int lds = NORM ? G::LDS_NORM : G::LDS;
     static bool attr_set = false;
     if (!attr_set) {
-        ADVS_HIP(hipFuncSetAttribute((const void*)conv3x3_halo2_kernel<T, G, NT, XT>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+        ADVS_HIP(hipFuncSetAttribute((const void*)conv3x3_halo2_kernel<T, G, NT, XT, NORM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
     p.nMt = p.B * (p.H / G::TY) * (p.W / G::TX);
     p.nNt = cdiv(p.Cout, 128);
-    conv3x3_halo2_kernel<T, G, NT, XT><<<p.nMt * (NT == 9 ? 1 : 4) * p.nNt, G::NTHR, G::LDS, st>>>(p);
+    conv3x3_halo2_kernel<T, G, NT, XT, NORM><<<p.nMt * (NT == 9 ? 1 : 4) * p.nNt, G::NTHR, lds, st>>>(p);
     ADVS_CHECK_LAUNCH("conv3x3_halo2");
     return ADVS_OK;
 }
@@ -380,6 +448,11 @@ static int h2_kind(ConvKP& p, int kind, hipStream_t st) {
 int conv_halo2_dispatch(ConvKP& p, int dtype, int tile, int kind, hipStream_t st) {
     ADVS_REQUIRE(conv_halo2_eligible(p, dtype, tile, kind),
                  "conv2d: tiles 17-19 (second-generation halo kernels) need a 16-bit dtype, 3x3 stride 1 pad 1, H a multiple of 16 and W of %d", h2_tx(tile));
+    if (p.norm) {                                    // GroupNorm + SiLU on load: the 4-wave form only
+        ADVS_REQUIRE(tile == 19 && kind != 1 && p.C1 + p.C2 <= H2G256W4::NORM_MAXC, "conv2d: norm needs tile 19, no upsample, c1 + c2 <= %d", H2G256W4::NORM_MAXC);
+        if (dtype == ADVS_BF16) return kind == 2 ? h2_launch<BF16, H2G256W4, 9, true, true>(p, st) : h2_launch<BF16, H2G256W4, 9, false, true>(p, st);
+        return kind == 2 ? h2_launch<F16, H2G256W4, 9, true, true>(p, st) : h2_launch<F16, H2G256W4, 9, false, true>(p, st);
+    }
     if (dtype == ADVS_BF16) {
         if (tile == 17) return h2_kind<BF16, H2G512>(p, kind, st);
         if (tile == 18) return h2_kind<BF16, H2G256>(p, kind, st);

@@ -383,6 +383,7 @@ static int pick_tile(long long m_img, int cout) {
 // tiles 17-19 (conv_halo2.hip) by the descriptor alone: 16-bit, 3x3 stride 1 pad 1, plain or sub-pixel upsample, optional fused 1x1
 static bool halo2_args_ok(const advs_conv_args* a, int tile) {
     if (tile < 17 || tile > 19 || a->dtype == ADVS_F32 || a->relu_mask) return false;
+    if (a->norm && (tile != 19 || a->upsample || a->c1 + a->c2 > 384)) return false;     // GroupNorm + SiLU on load: tile 19 only
     if (!(a->ksize == 3 && a->stride == 1 && a->pad == 1 && a->h % 16 == 0 && a->w_ % (tile == 17 ? 32 : 16) == 0)) return false;
     if ((long long)a->b * a->h * a->w_ >= (1ll << 28)) return false;
     if (a->upsample == ADVS_UPSAMPLE_SUBPIXEL) return !a->e1;
@@ -390,6 +391,7 @@ static bool halo2_args_ok(const advs_conv_args* a, int tile) {
 }
 static int resolve_tile(const advs_conv_args* a, long long m_img) {
     const int want = g_tile_override ? g_tile_override : a->tile;
+    if (a->norm) return halo2_args_ok(a, 19) ? 19 : -1;          // the fused form exists in one kernel only (advs_conv2d rejects -1)
     if (halo2_args_ok(a, want)) return want;
     // Second-generation halo kernels wherever they apply (16-bit, 3x3 stride 1; plain, sub-pixel upsample or fused 1x1 operand).  Measured
     // round 3 (tools/conv_one.py --suite, profiles/round3_halo2.txt): from 128 x 128 maps up the 4-wave form with two workgroups per CU
@@ -449,6 +451,7 @@ extern "C" int advs_conv2d(const advs_conv_args* a, void* stream) {
     p.stats = a->stats;
     p.fast_epi = 0;
     p.mask = (const char*)a->relu_mask;
+    p.norm = a->norm;
     ADVS_REQUIRE(!a->relu_mask || (!a->stats && a->upsample != ADVS_UPSAMPLE_SUBPIXEL && (a->tile == 0 || a->tile == 1 || a->tile == 4 || a->tile == 15 || a->tile == 16)),
                  "conv2d: relu_mask needs a per-tap tile (0, 1, 4, 15 or 16), no stats, no sub-pixel upsample");
     p.B = a->b; p.H = a->h; p.W = a->w_; p.C1 = a->c1; p.C2 = a->c2; p.Cout = a->cout;
@@ -482,6 +485,7 @@ extern "C" int advs_conv2d(const advs_conv_args* a, void* stream) {
     p.act = a->act; p.temb_stride = a->temb_stride > 0 ? a->temb_stride : a->cout;
     p.dHoWo.init((unsigned)(p.Ho * p.Wo)); p.dWo.init((unsigned)p.Wo);
     int tile = resolve_tile(a, (long long)p.Ho * p.Wo);
+    ADVS_REQUIRE(tile >= 0, "conv2d: norm (GroupNorm + SiLU on load) needs a 16-bit dtype, 3x3 stride 1 pad 1, no upsample, h and w multiples of 16, c1 + c2 <= 384");
     const int h2kind = subpixel ? 1 : (p.e1 ? 2 : 0);
     if (tile >= 17 && tile <= 19 && !conv_halo2_eligible(p, a->dtype, tile, h2kind)) {
         ADVS_REQUIRE(g_tile_override != 0, "conv2d: tile %d (second-generation halo kernel) cannot take this shape", tile);

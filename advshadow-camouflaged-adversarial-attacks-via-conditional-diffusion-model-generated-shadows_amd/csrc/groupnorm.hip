@@ -89,6 +89,41 @@ gn_partial_kernel(const T* __restrict__ x, const T* __restrict__ x2, int C1, flo
     }
 }
 
+// Per-group mean / rstd of sample b from the chunk partials: LPG lanes per group walk the chunks (fixed interleave, loads issued
+// together), then a butterfly: G <= 32 groups x 8 lanes, or G <= 64 groups x 4 lanes = 256 threads.  Shared by the apply pass and
+// the (scale, shift) table of the fused form, so both see the same bits.
+__device__ __forceinline__ void gn_combine_partials(const float* __restrict__ partials, int b, int tid, int HW, int cpg, int G,
+                                                    int nchunk, float* s_mean, float* s_rstd) {
+    const int lsh = G <= 32 ? 3 : 2, LPG = 1 << lsh;
+    const int g = tid >> lsh, sub = tid & (LPG - 1);
+    double a = 0.0, d = 0.0;
+    if (g < G) {
+        const float2* p = (const float2*)partials + ((size_t)b * nchunk * G + g);
+        int k = sub;
+        for (; k + 3 * LPG < nchunk; k += 4 * LPG) {
+            const float2 e0 = p[(size_t)k * G], e1 = p[(size_t)(k + LPG) * G], e2 = p[(size_t)(k + 2 * LPG) * G],
+                         e3 = p[(size_t)(k + 3 * LPG) * G];
+            a += (double)e0.x; d += (double)e0.y; a += (double)e1.x; d += (double)e1.y;
+            a += (double)e2.x; d += (double)e2.y; a += (double)e3.x; d += (double)e3.y;
+        }
+        for (; k < nchunk; k += LPG) { const float2 e = p[(size_t)k * G]; a += (double)e.x; d += (double)e.y; }
+    }
+    a += __shfl_xor(a, 1); d += __shfl_xor(d, 1);
+    a += __shfl_xor(a, 2); d += __shfl_xor(d, 2);
+    if (lsh == 3) { a += __shfl_xor(a, 4); d += __shfl_xor(d, 4); }
+    if (g < G && sub == 0) {
+        double n = (double)HW * cpg, mean = a / n, var = d / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        s_mean[g] = (float)mean;
+        s_rstd[g] = (float)(1.0 / sqrt(var + 1e-5));
+    }
+}
+// scale / shift of channel c: y = fma(x, scale, shift).  One definition for the apply pass and the fused form's table.
+__device__ __forceinline__ void gn_channel_affine(float mean, float rstd, float gamma, float beta, float& scale, float& shift) {
+    scale = rstd * gamma;
+    shift = fmaf(-mean, scale, beta);
+}
+
 // FAST: the dominant launch of the eps-predictor -- GroupNorm + SiLU, no residual, no per-channel add, 16-bit
 // storage -- with the activation fixed at compile time (no per-element dispatch, no dead adds).
 template <typename T, bool FAST>
@@ -107,31 +142,7 @@ gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ x2, int C1, const
             s_rstd[g] = meanrstd[((size_t)b * G + g) * 2 + 1];
         }
     } else {
-        // LPG lanes per group walk the chunk partials (fixed interleave, loads issued together), then a butterfly:
-        // G <= 32 groups x 8 lanes, or G <= 64 groups x 4 lanes = 256 threads
-        const int lsh = G <= 32 ? 3 : 2, LPG = 1 << lsh;
-        const int g = tid >> lsh, sub = tid & (LPG - 1);
-        double a = 0.0, d = 0.0;
-        if (g < G) {
-            const float2* p = (const float2*)partials + ((size_t)b * nchunk * G + g);
-            int k = sub;
-            for (; k + 3 * LPG < nchunk; k += 4 * LPG) {
-                const float2 e0 = p[(size_t)k * G], e1 = p[(size_t)(k + LPG) * G], e2 = p[(size_t)(k + 2 * LPG) * G],
-                             e3 = p[(size_t)(k + 3 * LPG) * G];
-                a += (double)e0.x; d += (double)e0.y; a += (double)e1.x; d += (double)e1.y;
-                a += (double)e2.x; d += (double)e2.y; a += (double)e3.x; d += (double)e3.y;
-            }
-            for (; k < nchunk; k += LPG) { const float2 e = p[(size_t)k * G]; a += (double)e.x; d += (double)e.y; }
-        }
-        a += __shfl_xor(a, 1); d += __shfl_xor(d, 1);
-        a += __shfl_xor(a, 2); d += __shfl_xor(d, 2);
-        if (lsh == 3) { a += __shfl_xor(a, 4); d += __shfl_xor(d, 4); }
-        if (g < G && sub == 0) {
-            double n = (double)HW * cpg, mean = a / n, var = d / n - mean * mean;
-            if (var < 0.0) var = 0.0;
-            s_mean[g] = (float)mean;
-            s_rstd[g] = (float)(1.0 / sqrt(var + 1e-5));
-        }
+        gn_combine_partials(partials, b, tid, HW, cpg, G, nchunk, s_mean, s_rstd);
     }
     __syncthreads();
     const int pl = tid / vpp, cv = tid - pl * vpp;
@@ -140,9 +151,7 @@ gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ x2, int C1, const
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
         int c = cv * VEC + j, g = c / cpg;
-        float a = s_rstd[g] * gamma[c];
-        ca[j] = a;
-        cb[j] = beta[c] - s_mean[g] * a;
+        gn_channel_affine(s_mean[g], s_rstd[g], gamma[c], beta[c], ca[j], cb[j]);
         cc[j] = cadd ? cadd[(size_t)b * cadd_stride + c] : 0.f;
     }
     const int per = (HW + nblk - 1) / nblk;
@@ -259,6 +268,49 @@ gn_stats_fold_kernel(const float* __restrict__ st1, int rbpi1, int C1, const flo
     }
 }
 
+// (scale, shift) per (sample, channel) for advs_conv_args.norm: the coefficients gn_apply_kernel would use
+__global__ void __launch_bounds__(GN_THREADS)
+gn_affine_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ partials,
+                 float* __restrict__ table, int HW, int C, int G, int nchunk) {
+    __shared__ float s_mean[64], s_rstd[64];
+    const int b = blockIdx.x, tid = threadIdx.x, cpg = C / G;
+    gn_combine_partials(partials, b, tid, HW, cpg, G, nchunk, s_mean, s_rstd);
+    __syncthreads();
+    for (int c = tid; c < C; c += GN_THREADS) {
+        float sc, sh;
+        gn_channel_affine(s_mean[c / cpg], s_rstd[c / cpg], gamma[c], beta[c], sc, sh);
+        *(float2*)(table + ((size_t)b * C + c) * 2) = make_float2(sc, sh);
+    }
+}
+
+static int gn_fold_chunks(int rbpi1, int rbpi2) {
+    const int rbmax = rbpi1 > rbpi2 ? rbpi1 : rbpi2;
+    // a FIXED number of chunks (not a function of the batch): the rounding points of the per-chunk f32 partials,
+    // and with them the statistics of an image, do not depend on which batch the image is evaluated in.
+    // 32 x batch workgroups: the fold is latency-bound, a full-size batch fills the chip four times over.
+    int nchunk = 32;
+    if (nchunk > rbmax / 8) nchunk = rbmax / 8;
+    if (nchunk > GN_MAX_CHUNKS) nchunk = GN_MAX_CHUNKS;
+    if (nchunk < 1) nchunk = 1;
+    return nchunk;
+}
+
+extern "C" int advs_groupnorm_affine_stats(const float* stats1, int rbpi1, const float* stats2, int rbpi2, const float* gamma,
+                                           const float* beta, void* scratch, float* table, int b, int hw, int c1, int c2,
+                                           int groups, void* stream) {
+    ADVS_REQUIRE(stats1 && rbpi1 > 0 && gamma && beta && scratch && table, "groupnorm_affine_stats: null pointer");
+    ADVS_REQUIRE(c1 > 0 && c2 >= 0 && (c2 == 0) == (stats2 == nullptr), "groupnorm_affine_stats: c2/stats2 mismatch");
+    const int c = c1 + c2;
+    ADVS_REQUIRE(b > 0 && hw > 0 && groups > 0 && groups <= 64 && c % groups == 0 && c <= GNF_MAXC, "groupnorm_affine_stats: bad shape");
+    const int nchunk = gn_fold_chunks(rbpi1, rbpi2);
+    hipStream_t st = (hipStream_t)stream;
+    gn_stats_fold_kernel<<<dim3(nchunk, b), 256, 0, st>>>(stats1, rbpi1, c1, stats2, rbpi2, c2, (float*)scratch, groups, nchunk);
+    ADVS_CHECK_LAUNCH("gn_stats_fold");
+    gn_affine_kernel<<<b, GN_THREADS, 0, st>>>(gamma, beta, (const float*)scratch, table, hw, c, groups, nchunk);
+    ADVS_CHECK_LAUNCH("gn_affine");
+    return ADVS_OK;
+}
+
 template <typename T>
 static int gn_launch(const void* x, const void* x2, int c1, const float* gamma, const float* beta, const void* res,
                      void* y, float* partials, int b, int hw, int c, int groups, int act, const float* cadd,
@@ -269,14 +321,7 @@ static int gn_launch(const void* x, const void* x2, int c1, const float* gamma, 
     const float* meanrstd = nullptr;
     int nchunk = 1;
     if (st1) {
-        const int rbmax = rbpi1 > rbpi2 ? rbpi1 : rbpi2;
-        // a FIXED number of chunks (not a function of the batch): the rounding points of the per-chunk f32 partials,
-        // and with them the statistics of an image, do not depend on which batch the image is evaluated in.
-        // 32 x batch workgroups: the fold is latency-bound, a full-size batch fills the chip four times over.
-        nchunk = 32;
-        if (nchunk > rbmax / 8) nchunk = rbmax / 8;
-        if (nchunk > GN_MAX_CHUNKS) nchunk = GN_MAX_CHUNKS;
-        if (nchunk < 1) nchunk = 1;
+        nchunk = gn_fold_chunks(rbpi1, rbpi2);
         gn_stats_fold_kernel<<<dim3(nchunk, b), 256, 0, st>>>(st1, rbpi1, c1, st2, rbpi2, c - c1, partials, groups, nchunk);
         ADVS_CHECK_LAUNCH("gn_stats_fold");
     } else {

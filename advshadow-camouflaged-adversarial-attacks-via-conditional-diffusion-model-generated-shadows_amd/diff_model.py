@@ -111,6 +111,7 @@ class UNetModel(nn.Module):
         self.num_res_blocks, self.attention_resolutions = num_res_blocks, tuple(attention_resolutions)
         self.dropout, self.channel_mult, self.conv_resample, self.num_heads = dropout, tuple(channel_mult), True, num_heads
         self.compute_dtype, self.use_graph = compute_dtype, use_graph
+        self.fuse_norm = True          # 16-bit modes: GroupNorm + SiLU inside the conv that reads it where the shape allows (engine.Builder.can_fuse_norm)
         ted = 4 * model_channels
         self.layout = unet_layout(model_channels, self.channel_mult, num_res_blocks, self.attention_resolutions, in_channels)
         # parameter holders, created in the reference's order so a seeded construction matches it
@@ -283,20 +284,30 @@ def emit_unet_forward(bld, model, W, x_nchw, t_dev, eps_out):
     temb = bld.linear(emb, W["temb_w"], W["temb_b"], act_in="silu")          # [B, sum cout]
     tstride = W["temb_total"]
 
+    fuse = getattr(model, "fuse_norm", True)
+
+    def norm_silu_conv(x1, x2, gk, wk, cout, **kw):
+        """conv3x3(SiLU(GroupNorm32(cat[x1, x2]))) (diff_model.py:70-73, 83-86): on the large single-tile maps the norm is applied
+        inside the conv while its halo is staged (bit-identical to the two passes), elsewhere as its own pass."""
+        if fuse and bld.can_fuse_norm(x1, x2, cout):
+            tab = bld.groupnorm_affine(x1, W[gk + ".g"], W[gk + ".b"], 32, x2=x2)
+            y = bld.conv(x1, W[wk + ".w"], cout, x2=x2, bias=W[wk + ".b"], norm=tab, want_stats=True, **kw)
+            bld.free(tab)
+            return y
+        a = bld.groupnorm(x1, W[gk + ".g"], W[gk + ".b"], 32, act="silu", x2=x2)
+        y = bld.conv(a, W[wk + ".w"], cout, bias=W[wk + ".b"], want_stats=True, **kw)
+        bld.free(a)
+        return y
+
     def res_block(p, cin, cout, x1, x2):
-        a1 = bld.groupnorm(x1, W[p + ".conv1.0.g"], W[p + ".conv1.0.b"], 32, act="silu", x2=x2)
         o = W["temb_off"][p]
-        h1 = bld.conv(a1, W[p + ".conv1.2.w"], cout, bias=W[p + ".conv1.2.b"], temb=temb[:, o:o + cout], temb_stride=tstride,
-                      want_stats=True)
-        bld.free(a1)
-        a2 = bld.groupnorm(h1, W[p + ".conv2.0.g"], W[p + ".conv2.0.b"], 32, act="silu")
-        bld.free(h1)
+        h1 = norm_silu_conv(x1, x2, p + ".conv1.0", p + ".conv1.2", cout, temb=temb[:, o:o + cout], temb_stride=tstride)
         if cin != cout:     # conv2(h) + shortcut(cat[x1, x2]) as one implicit GEMM over K = [9*cout | cin]
-            y = bld.conv(a2, W[p + ".conv2.3.w"], cout, bias=W[p + ".conv2.3.b"], extra=(x1, x2), want_stats=True)
+            y = norm_silu_conv(h1, None, p + ".conv2.0", p + ".conv2.3", cout, extra=(x1, x2))
         else:
             assert x2 is None
-            y = bld.conv(a2, W[p + ".conv2.3.w"], cout, bias=W[p + ".conv2.3.b"], residual=x1, want_stats=True)
-        bld.free(a2)
+            y = norm_silu_conv(h1, None, p + ".conv2.0", p + ".conv2.3", cout, residual=x1)
+        bld.free(h1)
         return y
 
     def attn_block(p, ch, x):

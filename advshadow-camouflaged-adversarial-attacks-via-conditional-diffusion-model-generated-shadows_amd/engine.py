@@ -143,8 +143,10 @@ class Builder:
     # ---- ops (activations are NHWC tensors [B,H,W,C] of the compute dtype)
     def conv(self, x1, w, cout, *, x2=None, bias=None, temb=None, temb_stride=0, residual=None,
              ksize=3, stride=1, pad=1, upsample=False, act=None, out=None, tile=0, want_stats=False, extra=None,
-             residual_after_act=False, relu_mask=None):
+             residual_after_act=False, relu_mask=None, norm=None):
         """relu_mask: forward activation whose ReLU backward is fused into this (data-gradient) conv.
+        norm: (scale, shift) table from ``groupnorm_affine`` -- the conv reads SiLU(GroupNorm(cat[x1, x2])) computed while the
+        halo is staged (include/advshadow.h: advs_conv_args.norm).
         extra = (e1, e2_or_None): NHWC tensors at the OUTPUT resolution whose 1x1 conv is summed in;
         ``w`` then holds [taps * (C1 + C2) | E1 + E2] per output channel."""
         B, H, W, L1 = x1.shape
@@ -163,7 +165,7 @@ class Builder:
                      ACT[act] | (GN_RESIDUAL_AFTER_ACT if residual_after_act else 0), self.dt, temb_stride, tile, 0, 0,
                      ptr(extra[0]) if extra else 0, ptr(extra[1]) if extra and extra[1] is not None else 0,
                      extra[0].shape[3] if extra else 0, extra[1].shape[3] if extra and extra[1] is not None else 0,
-                     L1 if L1 != C1 else 0, L2 if L2 != C2 else 0, ptr(relu_mask))
+                     L1 if L1 != C1 else 0, L2 if L2 != C2 else 0, ptr(relu_mask), ptr(norm))
         kw = 16 * (C1 + C2) if subpixel else ksize * ksize * (C1 + C2) + a.ce1 + a.ce2
         if w.numel() != cout * kw:
             raise ValueError(f"conv: packed weight has {w.numel()} elements, expected {cout} x {kw} "
@@ -177,7 +179,7 @@ class Builder:
                 stats = self.buf((B * Ho * Wo // rows, cout, 2), torch.float32)
                 self.stats[y.data_ptr()] = (stats, Ho * Wo // rows)
                 a.stats, a.stats_rows = ptr(stats), rows
-        self.plan.add(self.lib.advs_conv2d, C.byref(a), keep=(a, x1, x2, w, bias, temb, residual, y, stats, extra, relu_mask))
+        self.plan.add(self.lib.advs_conv2d, C.byref(a), keep=(a, x1, x2, w, bias, temb, residual, y, stats, extra, relu_mask, norm))
         return y
 
     def conv_first(self, x_nchw, w, bias, cout, want_stats=False):
@@ -216,6 +218,32 @@ class Builder:
                       chan_add_stride, ptr(y), ptr(self.gn_scratch), B, H * W, C1, C2, groups, actc, self.dt,
                       keep=(x, x2, gamma, beta, residual, chan_add, y))
         return y
+
+    NORM_MAXC = 384              # csrc/conv_halo2.hip: H2Geom::NORM_MAXC
+
+    def can_fuse_norm(self, x, x2, cout, ksize=3):
+        """GroupNorm + SiLU applied inside the conv that reads it (advs_conv_args.norm)?  16-bit storage, a 3x3 conv on a map the
+        4-wave halo tile takes (>= 128 x 128, multiples of 16), one 128-channel output tile -- with two the transform would run
+        twice per element -- at most NORM_MAXC input channels, statistics of every source available from its producer."""
+        B, H, W, C1 = x.shape
+        C2 = 0 if x2 is None else x2.shape[3]
+        if self.dt == F32 or ksize != 3 or cout > 128 or C1 + C2 > self.NORM_MAXC or C1 % 64 or C2 % 64:
+            return False
+        if H % 16 or W % 16 or H * W < 128 * 128:
+            return False
+        return x.data_ptr() in self.stats and (x2 is None or x2.data_ptr() in self.stats)
+
+    def groupnorm_affine(self, x, gamma, beta, groups, x2=None):
+        """The [B][C][2] (scale, shift) table of GroupNorm(groups)(cat[x, x2]) from the producers' epilogue statistics."""
+        B, H, W, C1 = x.shape
+        C2 = 0 if x2 is None else x2.shape[3]
+        s1 = self.stats[x.data_ptr()]
+        s2 = self.stats[x2.data_ptr()] if x2 is not None else None
+        table = self.buf((B, C1 + C2, 2), torch.float32)
+        self.plan.add(self.lib.advs_groupnorm_affine_stats, ptr(s1[0]), s1[1], ptr(s2[0]) if s2 else 0, s2[1] if s2 else 0,
+                      ptr(gamma), ptr(beta), ptr(self.gn_scratch), ptr(table), B, H * W, C1, C2, groups,
+                      keep=(x, x2, s1, s2, gamma, beta, table))
+        return table
 
     def maxpool2(self, x):
         B, H, W, Cc = x.shape

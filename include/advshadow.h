@@ -74,9 +74,11 @@ typedef struct advs_conv_args {
     int temb_stride;                    /* floats between consecutive samples' temb rows    */
     int tile;                           /* 0 = choose; 1: 128x128, 2|3: 256x128, 4: 256x256,
                                            10: 16x16-pixel halo tile (3x3 stride 1 only); 12 (implied by
-                                           ADVS_UPSAMPLE_SUBPIXEL): its 4-tap sub-pixel form; 14: 16x32-pixel
-                                           halo tile, one wave per SIMD (16-bit, experimental, never chosen);
-                                           15: 64x128, 16: 64x64 (chosen for maps of <= 56x56 / 14x14 pixels)  */
+                                           ADVS_UPSAMPLE_SUBPIXEL): its 4-tap sub-pixel form;
+                                           15: 64x128, 16: 64x64 (chosen for maps of <= 56x56 / 14x14 pixels);
+                                           17 | 18 | 19: second-generation halo tiles (16-bit, 3x3 stride 1, plain /
+                                           sub-pixel / fused 1x1): 16x32 pixels x 8 waves, 16x16 x 8 waves, 16x16 x 4
+                                           waves with two workgroups per CU (chosen from 64x64 maps up)          */
     float* stats;                       /* NULL, or [ceil(M/rows)][cout][2]: per row block (rows =
                                            advs_conv_tile_rows(tile), must divide ho*wo) and channel the
                                            (sum, sum of squares) of y as stored -> advs_groupnorm_stats */
@@ -94,6 +96,12 @@ typedef struct advs_conv_args {
                                            residual / act -- ReLU backward fused into a data-gradient conv (the mask is the
                                            forward activation behind the ReLU; train_shadow.py:209 loss.backward()).
                                            Per-tap tiles only (tile 0 | 1 | 4), no stats.                                */
+    const float* norm;                  /* NULL, or [b][c1+c2][2] f32 (scale, shift) from advs_groupnorm_affine_stats: the conv reads
+                                           SiLU(scale * x + shift) in place of x -- GroupNorm + SiLU of the conv's input applied while
+                                           the halo is staged, zero padding staying zero (norm_layer + SiLU + Conv2d, diff_model.py:70-73,
+                                           83-86): no normalised tensor in HBM.  Values are rounded to the storage dtype exactly as
+                                           advs_groupnorm_stats would have stored them, so the result is bit-identical to the two-pass
+                                           form.  16-bit dtypes, 3x3 stride 1 pad 1, tile 19's shapes, c1 + c2 <= 384.          */
 } advs_conv_args;
 int advs_conv2d(const advs_conv_args* a, void* stream);
 int advs_conv_set_tile(int tile);       /* tuning hook: non-zero overrides every call's tile  */
@@ -139,6 +147,13 @@ int advs_groupnorm_stats(const void* x, const void* x2, const float* stats1, int
                          const float* beta, const void* residual_in, const float* chan_add,
                          int chan_add_stride, void* y, void* scratch, int b, int hw, int c, int c2,
                          int groups, int act, int dtype, void* stream);
+
+/* The (scale, shift) table of GroupNorm(groups) + affine for advs_conv_args.norm, from the same epilogue statistics
+ * advs_groupnorm_stats folds: table[b][c][0] = rstd_g * gamma_c, [1] = beta_c - mean_g * rstd_g * gamma_c.
+ * scratch as for advs_groupnorm_stats.  table: b * (c + c2) * 2 floats.                                         */
+int advs_groupnorm_affine_stats(const float* stats1, int row_blocks_per_image1, const float* stats2,
+                                int row_blocks_per_image2, const float* gamma, const float* beta, void* scratch,
+                                float* table, int b, int hw, int c, int c2, int groups, void* stream);
 
 /* ---- resampling / token norm of the class-conditional UNet -----------------------------
  * MaxPool2d(2) (model/modules/block.py:27); y is [b][h/2][w/2][c].                          */

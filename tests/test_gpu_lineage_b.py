@@ -245,3 +245,26 @@ def test_teacher_forced_16bit_at_256_vs_oracle(dt, emax, emean):
         worst.append((t, round(err.max().item(), 5), round(err.mean().item(), 6)))
     print("teacher-forced 256", dt, worst)
     assert all(m < emax and a < emean for _, m, a in worst), worst
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+def test_norm_inside_conv_is_bit_identical_to_two_passes(dt):
+    """Round 3: on the >= 128 x 128 single-tile layers the 16-bit plans apply GroupNorm + SiLU inside the conv that reads it
+    (advs_conv_args.norm, csrc/conv_halo2.hip) instead of writing the normalised tensor.  Same statistics, same coefficient
+    arithmetic, same rounding: the whole forward must not change by one bit (default UNetModel, 2x3x128x128 -- level 0 is
+    128 x 128, every ResidualBlock shape of that level: K = 1152 / 2304 / 3456, temb, identity and fused 1x1 shortcut)."""
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn(2, 3, 128, 128, generator=g).cuda()
+    tt = torch.tensor([981, 21], dtype=torch.long, device="cuda")
+    outs = []
+    for fuse in (True, False):
+        torch.manual_seed(0)
+        net = UNetModel(compute_dtype=dt).to("cuda").eval()
+        net.fuse_norm = fuse
+        eng = net.engine(2, 128)
+        names = [fn.__name__ for fn, _ in eng.plan.ops]
+        assert ("advs_groupnorm_affine_stats" in names) == fuse
+        outs.append(net(x, tt).cpu())
+        del net, eng
+        torch.cuda.empty_cache()
+    assert torch.equal(outs[0], outs[1]), (outs[0] - outs[1]).abs().max().item()

@@ -496,6 +496,79 @@ def test_conv2d_extra_operand_on_the_halo_kernel(case, dt, tile):
     assert rel < tol(dt, 2e-5, 1e-2), rel
 
 
+# ------------------------------------------------------------------------------ GroupNorm + SiLU inside the conv (advs_conv_args.norm)
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", [
+    # B, H, W, (C1, C2), Cout, temb, residual, (E1, E2)
+    (2, 32, 32, (128, 0), 128, 1, 0, (0, 0)),          # ResidualBlock.conv1 at level 0: fast epilogue
+    (1, 32, 48, (128, 256), 128, 1, 0, (0, 0)),        # up path: norm over the concat [h, skip], 12 units
+    (2, 16, 32, (128, 0), 128, 0, 1, (0, 0)),          # conv2 with the identity shortcut: generic epilogue
+    (1, 32, 32, (128, 0), 128, 0, 0, (128, 256)),      # conv2 with the fused 1x1 shortcut: extra units stay un-normalised
+    (3, 16, 16, (64, 0), 64, 1, 0, (0, 0)),            # two units, N tail, image edges everywhere
+])
+def test_conv2d_norm_on_load(case, dt):
+    """conv3x3(SiLU(GroupNorm32(x))) with the norm applied while the halo is staged must equal, BIT FOR BIT, the two-pass form
+    (advs_groupnorm_stats, then advs_conv2d on its output): same statistics, same coefficient arithmetic, same rounding of the
+    normalised activation.  Also against the torch oracle (norm_layer + SiLU + Conv2d, diff_model.py:70-73)."""
+    B, H, W, (C1, C2), Cout, has_t, has_r, (E1, E2) = case
+    code = dtype_code(dt)
+    r = lambda t: lp_round(dt, t)
+    src = [rnd(B, c, H, W, seed=131 + i) * (1.0 + 0.5 * i) + 0.3 * i for i, c in enumerate((C1, C2)) if c]
+    prods = []
+    op = OneOp(dt, B)
+    for i, xs in enumerate(src):           # each source is a conv output, so that its statistics come from an epilogue
+        c = xs.shape[1]
+        wi = rnd(c, 64, 1, 1, seed=141 + i, scale=0.2)
+        xi = rnd(B, 64, H, W, seed=151 + i)
+        prods.append(op.b.conv(nhwc(xi, dt), pack_conv_weight(wi.to(dev()), code), c, ksize=1, pad=0, want_stats=True))
+    x1, x2 = prods[0], (prods[1] if C2 else None)
+    C = C1 + C2
+    gamma, beta = rnd(C, seed=161) * 0.3 + 1, rnd(C, seed=162) * 0.2
+    w3 = rnd(Cout, C, 3, 3, seed=163, scale=1 / math.sqrt(9 * C))
+    bias = rnd(Cout, seed=164)
+    temb = rnd(B, Cout, seed=165) if has_t else None
+    res = rnd(B, Cout, H, W, seed=166) if has_r else None
+    e = [rnd(B, c, H, W, seed=171 + i) for i, c in enumerate((E1, E2)) if c]
+    wp = pack_conv_weight(w3.to(dev()), code)
+    if e:
+        w1 = rnd(Cout, E1 + E2, 1, 1, seed=173, scale=1 / math.sqrt(E1 + E2))
+        wp = torch.cat([wp.reshape(Cout, -1), pack_conv_weight(w1.to(dev()), code).reshape(Cout, -1)], 1).contiguous()
+    kw = dict(bias=bias.to(dev()), temb=temb.to(dev()) if has_t else None, temb_stride=Cout if has_t else 0,
+              residual=nhwc(res, dt) if has_r else None,
+              extra=(nhwc(e[0], dt), nhwc(e[1], dt) if len(e) > 1 else None) if e else None)
+    g, be = gamma.to(dev()), beta.to(dev())
+    two = op.b.conv(op.b.groupnorm(x1, g, be, 32, act="silu", x2=x2), wp, Cout, tile=19, want_stats=True, **kw)
+    tab = op.b.groupnorm_affine(x1, g, be, 32, x2=x2)
+    one = op.b.conv(x1, wp, Cout, x2=x2, norm=tab, want_stats=True, **kw)
+    assert op.b.lib.advs_conv_resolve_tile(op.b.plan.ops[-1][1][0]) == 19
+    op.go()
+    assert torch.equal(one.view(torch.int16), two.view(torch.int16)), (one.float() - two.float()).abs().max().item()
+    s1, s2 = op.b.stats[one.data_ptr()][0], op.b.stats[two.data_ptr()][0]
+    assert torch.equal(s1, s2)
+    # and the torch restatement on the stored producers
+    xin = torch.cat([nchw(t) for t in (x1, x2) if t is not None], 1)
+    a = r(F.silu(F.group_norm(xin, 32, gamma, beta, eps=1e-5)))
+    ref = F.conv2d(a, r(w3), bias, padding=1)
+    if e:
+        ref = ref + F.conv2d(r(torch.cat(e, 1)), r(w1))
+    if has_t:
+        ref = ref + temb[:, :, None, None]
+    if has_r:
+        ref = ref + r(res)
+    err = (nchw(one) - ref).abs().max().item()
+    assert err < 6e-2, err
+
+
+def test_conv2d_norm_on_load_rejects_what_it_cannot_take():
+    op = OneOp("fp32", 1)
+    x = torch.zeros(1, 16, 16, 32, device=dev())
+    w = pack_conv_weight(torch.zeros(32, 32, 3, 3, device=dev()), dtype_code("fp32"))
+    tab = torch.zeros(1, 32, 2, device=dev())
+    op.b.conv(x, w, 32, norm=tab)
+    fn, args = op.b.plan.ops[-1]
+    assert fn(*args, op.stream.cuda_stream) != 0 and "norm" in op.b.lib.advs_last_error().decode()
+
+
 # ------------------------------------------------------------------------------ CSPDarkUnet additions
 @pytest.mark.parametrize("tile", [0, 1, 4, 10])
 @pytest.mark.parametrize("case", [
