@@ -148,6 +148,9 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise AdvsError(f"{LIB_PATH} is missing: build it with __graft_entry__.build() "
                             f"(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        if os.environ.get("ADVS_LIB_PATH"):
+            import sys
+            print(f"advshadow_amd: loading the library named by ADVS_LIB_PATH: {LIB_PATH}", file=sys.stderr)
         lib = C.CDLL(LIB_PATH)
         for name, args in SIGNATURES.items():
             fn = getattr(lib, name)

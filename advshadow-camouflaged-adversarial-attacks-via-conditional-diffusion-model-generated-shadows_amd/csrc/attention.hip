@@ -350,10 +350,13 @@ attn2_kernel(const AttnP p) {
         v_goff[i] = ch * 16;
         v_loff[i] = (ch * 8) * VS + kq * 8;
     }
-    if (ones_row) {                               // the commit below never touches rows >= d
-        T t1; Elt<T>::st(&t1, 1.0f);
-        const unsigned short one = t1.v;
-        for (int k = tid; k < KTS; k += AT_THREADS) *(unsigned short*)(sV + (size_t)d * VS + k * 2) = one;
+    // the commit below never touches V^T rows >= d: row d becomes the ones row, the rows behind it zeros (once, here) -- their
+    // O^T rows are never stored, but uninitialised LDS could feed NaN bit patterns through the P.V MFMA for nothing
+    for (int v = tid; v < (DMAX - d) * (KTS / 2); v += AT_THREADS) {
+        const int row = d + v / (KTS / 2), kp2 = v - (row - d) * (KTS / 2);
+        unsigned fill = 0u;
+        if (ones_row && row == d) { T t1; Elt<T>::st(&t1, 1.0f); fill = (unsigned)t1.v * 0x10001u; }
+        *(unsigned*)(sV + (size_t)row * VS + kp2 * 4) = fill;
     }
     auto fetch = [&](int k0) {
         const bool edge = k0 + KTS > p.N;

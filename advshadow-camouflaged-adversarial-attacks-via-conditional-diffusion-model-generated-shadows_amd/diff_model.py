@@ -456,6 +456,13 @@ class GaussianDiffusion:
         per = x[0].numel()
         s = torch.cuda.current_stream(dev).cuda_stream
         th = t.to("cpu", torch.int64).tolist()
+        if len(th) != x.shape[0]:
+            raise ValueError(f"t has {len(th)} entries for a batch of {x.shape[0]}")
+        if any(not 0 <= v < self.timesteps for v in th):
+            # the reference's a.gather(0, t) (diff_model.py:334-338) raises here; the kernel would read its tables out of bounds
+            raise IndexError(f"timestep out of range [0, {self.timesteps}): {[v for v in th if not 0 <= v < self.timesteps][:4]}")
+        if per % 4:
+            raise ValueError(f"one image has {per} elements: the fused update works on 16-byte vectors (a multiple of 4 floats)")
         i = 0
         while i < len(th):
             j = i

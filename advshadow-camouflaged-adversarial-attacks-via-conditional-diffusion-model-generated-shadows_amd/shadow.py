@@ -86,7 +86,10 @@ MAX_CONTOURS = 4096
 
 def cv_gray(mask):
     """``np.array(mask)`` + ``cv2.cvtColor(RGB2GRAY)`` for 3-channel masks (add_shadow.py:36-38, shadow_for_attack.py:26-28):
-    OpenCV's 8-bit fixed point (R*4899 + G*9617 + B*1868 + 8192) >> 14, which is NOT Pillow's ``convert('L')``."""
+    OpenCV's 8-bit fixed point (R*4899 + G*9617 + B*1868 + 8192) >> 14, which is NOT Pillow's ``convert('L')``.
+    (The 14-bit constants are those of OpenCV up to 4.x's generic 8-bit path; builds that take the 15-bit 9798 / 19235 / 3735
+    form can differ by one grey level on a few pixels, which matters to the contours only for near-black mask pixels.  cv2 is
+    absent from the image: parity unpinned either way)"""
     a = np.asarray(mask)
     if a.dtype == np.bool_:
         a = a.astype(np.uint8) * 255
@@ -107,15 +110,19 @@ def external_contours_batch(masks_u8):
     n, H, W = m.shape
     dev = m.device
     work = torch.empty(lib.advs_mask_contours_work_bytes(n, H, W), dtype=torch.uint8, device=dev)
-    out = torch.empty((n, MAX_CONTOURS, 8), dtype=torch.int32, device=dev)
-    cnt = torch.empty((n,), dtype=torch.int32, device=dev)
-    check(lib.advs_mask_contours(m.data_ptr(), n, H, W, work.data_ptr(), out.data_ptr(), cnt.data_ptr(), MAX_CONTOURS,
-                                 torch.cuda.current_stream(dev).cuda_stream), "mask_contours")
-    cnt_h = cnt.cpu().tolist()
+    cap = MAX_CONTOURS
+    while True:
+        out = torch.empty((n, cap, 8), dtype=torch.int32, device=dev)
+        cnt = torch.empty((n,), dtype=torch.int32, device=dev)
+        check(lib.advs_mask_contours(m.data_ptr(), n, H, W, work.data_ptr(), out.data_ptr(), cnt.data_ptr(), cap,
+                                     torch.cuda.current_stream(dev).cuda_stream), "mask_contours")
+        cnt_h = cnt.cpu().tolist()
+        most = max(cnt_h) if cnt_h else 0
+        if most <= cap:
+            break
+        cap = most              # a speckled mask (cv2.findContours just returns them all): once more with room for every contour
     res = []
     for i, c in enumerate(cnt_h):
-        if c > MAX_CONTOURS:
-            raise _lib.AdvsError(f"mask {i} has {c} external contours (limit {MAX_CONTOURS})")
         rows = out[i, :c].cpu().tolist()
         rows.sort(key=lambda e: -e[0])                       # last found first
         res.append([(e[1], e[2], e[3] - e[1] + 1, e[4] - e[2] + 1, e[6], e[0]) for e in rows])

@@ -101,7 +101,7 @@ def conv_traffic_from_profiles():
         d = json.load(f)
     n = fetch = write = 0.0
     for name, v in d.items():
-        if "conv_igemm_kernel" in name or "conv3x3_halo_kernel" in name:
+        if "conv_igemm_kernel" in name or "conv3x3_halo_kernel" in name or "conv3x3_halo2_kernel" in name:
             n += v["launches"]
             fetch += v["launches"] * v["FETCH_SIZE_KB_avg"] * 1024.0 * 2.0
             write += v["launches"] * (v["WRITE_SIZE_KB_avg"] or 0.0) * 1024.0
@@ -167,25 +167,45 @@ def free_port():
         return s.getsockname()[1]
 
 
-def self_launch(n, argv, script=None):
+def self_launch(n, argv, script=None, poll_s=0.2, grace_s=5.0):
     """Parent of a ``--gpus N`` run started without a launcher: N children, one rank per GPU.  Nothing here touches
     the GPU (no HIP call, no torch.cuda query that initialises it), so no exec-after-init hazard; rank 0's stdout is
-    relayed as this process's stdout, the other ranks' goes to stderr.  Returns the exit code."""
+    relayed as this process's stdout, the other ranks' goes to stderr.  Every child is polled: the first one that exits
+    non-zero ends the run -- the others (possibly parked in a collective that can no longer complete) are terminated, then
+    killed, and that exit code is returned.  Only the Popen objects created here are ever signalled."""
+    import threading
     port = free_port()
     procs = []
     for r in range(n):
         procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=child_env(r, n, port),
                                       stdout=subprocess.PIPE if r == 0 else 2))            # fd 2: the parent's stderr
-    out0, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        try:
-            p.wait(timeout=120 if rc == 0 else 5)
-        except subprocess.TimeoutExpired:
-            p.kill()                                            # exactly the child started above
-            p.wait()
-        rc = rc or p.returncode
-    for ln in out0.decode().splitlines():                      # the JSON line to stdout, library chatter to stderr
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()                                              # drain rank 0's pipe while every child is watched
+    rc = 0
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad:
+            rc = bad[0]
+            break
+        if all(c == 0 for c in codes):
+            break
+        time.sleep(poll_s)
+    if rc != 0:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        deadline = time.time() + grace_s
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()                                        # exactly the child started above
+                p.wait()
+    reader.join(timeout=grace_s)
+    out0 = chunks[0] if chunks else b""
+    for ln in out0.decode(errors="replace").splitlines():      # the JSON line to stdout, library chatter to stderr
         print(ln, file=sys.stdout if ln.lstrip().startswith("{") else sys.stderr)
     sys.stdout.flush()
     return rc
@@ -249,6 +269,7 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(self_launch(args.gpus, sys.argv[1:]))  # no GPU call has been made in this process
 
+    import datetime
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -256,46 +277,46 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus must agree")
     # one rank per GPU; ADVS_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (ranks
-    # then share devices and the control plane runs over gloo; the numbers of such a run mean nothing)
+    # then share devices and the control plane runs over gloo; the numbers of such a run mean nothing).
+    # ADVS_BENCH_STUB=1 (tests/test_parallel_cpu.py) replaces the GPU body -- sampler, attack shard -- by host stand-ins
+    # and keeps everything else: rendezvous, barriers, max-over-ranks timing, the gather, the JSON line.
     backend = os.environ.get("ADVS_BENCH_BACKEND", "nccl")
-    ndev = torch.cuda.device_count()
-    if world > 1 and backend == "nccl" and local >= ndev:
-        raise SystemExit(f"bench.py: LOCAL_RANK {local} but only {ndev} GPU(s) visible")
-    local_dev = local % max(ndev, 1)
-    torch.cuda.set_device(local_dev)
-    dev = torch.device("cuda", local_dev)
+    stub = os.environ.get("ADVS_BENCH_STUB") == "1"
+    if stub and backend == "nccl":
+        raise SystemExit("bench.py: ADVS_BENCH_STUB needs ADVS_BENCH_BACKEND=gloo (there is no GPU body to put on RCCL)")
+    attack_mode = args.pipeline == "attack"
+    B, S = args.batch or (64 if attack_mode else 32), args.size
+    if stub:
+        dev = torch.device("cpu")
+    else:
+        ndev = torch.cuda.device_count()
+        if world > 1 and backend == "nccl" and local >= ndev:
+            raise SystemExit(f"bench.py: LOCAL_RANK {local} but only {ndev} GPU(s) visible")
+        local_dev = local % max(ndev, 1)
+        torch.cuda.set_device(local_dev)
+        dev = torch.device("cuda", local_dev)
+    cdev = dev if backend == "nccl" else torch.device("cpu")    # where the collectives' tensors live
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # bounded: a rank that died before the rendezvous must not park the others for the default half hour
+        pg_timeout = datetime.timedelta(seconds=float(os.environ.get("ADVS_BENCH_PG_TIMEOUT_S", "300")))
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=pg_timeout)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=pg_timeout)
 
-    from advshadow_amd.diff_model import GaussianDiffusion, UNetModel
-
-    attack_mode = args.pipeline == "attack"
-    B, S = args.batch or (64 if attack_mode else 32), args.size
-
-    def build(dtype):
-        torch.manual_seed(0)                                    # random-init weights of the named architecture
-        return UNetModel(compute_dtype=dtype).to(dev).eval()
-
-    net = build(args.dtype)
-    gd = GaussianDiffusion()                                    # cosine schedule (diff_model.py:290)
-    g = torch.Generator().manual_seed(1234 + rank)              # images are indexed globally: rank r owns [r*B, (r+1)*B)
-    xT = torch.randn(B, 3, S, S, generator=g).to(dev)
-
-    def ddim_pass(model=None):
-        return gd.ddim_sample(model or net, S, batch_size=B, ddim_timesteps=args.ddim_steps, x_T=xT, return_tensor=True)
+    def sync_dev():
+        if not stub:
+            torch.cuda.synchronize(dev)
 
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        sync_dev()
 
     def timed(fn, steps, warmup):
-        """W untimed passes, then exactly K passes between barrier + synchronize; MAX over ranks."""
+        """W untimed passes, then exactly K passes between barrier + synchronize; MAX over ranks (and every rank's own time)."""
         out = None
         for _ in range(warmup):
             out = fn()
@@ -305,37 +326,100 @@ def main():
             out = fn()
         barrier()
         elapsed = time.perf_counter() - t0
+        per_rank = [elapsed]
         if world > 1:
-            tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+            every = [torch.empty_like(tt) for _ in range(world)]
+            dist.all_gather(every, tt)
+            per_rank = [float(e.item()) for e in every]
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
-        return elapsed, out
+        return elapsed, out, per_rank
 
-    if args.warmup == 0:
-        net.engine(B, S)                                        # build the plan outside the timed region
+    if stub:
+        from advshadow_amd import parallel
+
+        def ddim_pass(model=None):
+            time.sleep(0.01 * (rank + 1))                       # ranks differ: the reported time must be the slowest rank's
+            return torch.zeros(B, 3, 8, 8)
+
+        class _StubPipe:
+            def step(self):
+                total = B * world
+                lo, hi = parallel.shard_bounds(total, rank, world)
+                ids = torch.arange(lo, hi)
+                pred, psnr, ssim = parallel.gather_results((ids % 37).to(torch.int32), 10.0 + ids.float(), 1.0 / (1.0 + ids.float()), total)
+                return parallel.reduce_metrics(pred, torch.arange(total) % 37, psnr, ssim), pred
+
+        def make_pipe():
+            return _StubPipe()
+        net = gd = None
+    else:
+        from advshadow_amd.diff_model import GaussianDiffusion, UNetModel
+
+        def build(dtype):
+            torch.manual_seed(0)                                # random-init weights of the named architecture
+            return UNetModel(compute_dtype=dtype).to(dev).eval()
+
+        net = build(args.dtype)
+        gd = GaussianDiffusion()                                # cosine schedule (diff_model.py:290)
+        g = torch.Generator().manual_seed(1234 + rank)          # images are indexed globally: rank r owns [r*B, (r+1)*B)
+        xT_box = [torch.randn(B, 3, S, S, generator=g).to(dev)]
+
+        def ddim_pass(model=None):
+            return gd.ddim_sample(model or net, S, batch_size=B, ddim_timesteps=args.ddim_steps, x_T=xT_box[0], return_tensor=True)
+
+        def make_pipe():
+            pipe = AttackPipeline(net, gd, dev, rank, world, B, S, args.ddim_steps, args.dtype)
+            xT_box[0] = pipe.xT                                 # the sampler-only line of an attack run draws the same images
+            return pipe
+
+        if args.warmup == 0:
+            net.engine(B, S)                                    # build the plan outside the timed region
+
     workload = (f"DDIM-{args.ddim_steps} shadow generation, diff_model.UNetModel() defaults "
                 f"(35.7M params, random init seed 0), batch {B}/GPU, 3x{S}x{S}, cosine schedule, "
                 f"x_T resident in HBM, hipGraph-captured step, sample left on the device "
                 f"(the reference's final .cpu().numpy(), 25 MB per 32 images, is outside the timed region)")
-    extra_cfg = {}
+    attack_workload = (f"attack loop (BASELINE configs 2/3): DDIM-{args.ddim_steps} + uint8 cast + Pillow-exact resize 224 + ResNet-50 "
+                       f"victim (seed 1, 37 classes) + argmax, apply_shadow closed form (radius 40, intensity 0.43, blur 5) on synthetic "
+                       f"clean images + 64x64 PSNR/SSIM, all-gather of (pred, psnr, ssim) over {backend if world > 1 else 'no collective (1 rank)'} "
+                       f"+ ASR/PSNR/SSIM reduction; batch {B}/GPU, 3x{S}x{S}, default UNetModel, x_T resident in HBM")
+    extra_cfg, pipeline_attack = {}, None
     if attack_mode:
-        pipe = AttackPipeline(net, gd, dev, rank, world, B, S, args.ddim_steps, args.dtype)
-        xT = pipe.xT
-        d_elapsed, out = timed(ddim_pass, args.steps, max(args.warmup, 1))
-        elapsed, res = timed(pipe.step, args.steps, max(args.warmup, 1))
+        pipe = make_pipe()
+        d_elapsed, out, _ = timed(ddim_pass, args.steps, max(args.warmup, 1))
+        elapsed, res, per_rank = timed(pipe.step, args.steps, max(args.warmup, 1))
         metrics, pred = res
         assert metrics["n"] == B * world and pred.numel() == B * world
-        workload = (f"attack loop (BASELINE configs 2/3): DDIM-{args.ddim_steps} + uint8 cast + Pillow-exact resize 224 + ResNet-50 "
-                    f"victim (seed 1, 37 classes) + argmax, apply_shadow closed form (radius 40, intensity 0.43, blur 5) on synthetic "
-                    f"clean images + 64x64 PSNR/SSIM, all-gather of (pred, psnr, ssim) over {backend if world > 1 else 'no collective (1 rank)'} "
-                    f"+ ASR/PSNR/SSIM reduction; batch {B}/GPU, 3x{S}x{S}, default UNetModel, x_T resident in HBM")
+        workload = attack_workload
         extra_cfg = {"pipeline": "attack", "ddim_only_images_per_s": world * B * args.steps / d_elapsed,
                      "ddim_only_ms_per_step": 1e3 * d_elapsed / args.steps,
                      "post_sampling_ms_per_step": 1e3 * (elapsed - d_elapsed) / args.steps,
                      "asr": metrics["asr"], "psnr": metrics["psnr"], "ssim": metrics["ssim"]}
     else:
-        elapsed, out = timed(ddim_pass, args.steps, args.warmup)
+        elapsed, out, per_rank = timed(ddim_pass, args.steps, args.warmup)
         assert torch.isfinite(out).all().item(), "non-finite samples"
+        if world > 1:
+            # the driver's plain `--gpus N` form also exercises what the north_star names for N > 1: the whole attack loop of
+            # config 3 with its RCCL gather and the ASR / PSNR / SSIM reduction -- one warm-up and one timed pass behind the
+            # headline timing, reported beside it (never part of `value`)
+            pipe = make_pipe()
+            a_elapsed, res, a_per_rank = timed(pipe.step, 1, 1)
+            metrics, pred = res
+            assert metrics["n"] == B * world and pred.numel() == B * world
+            pipeline_attack = {"workload": attack_workload, "images": B * world, "ms_per_step": 1e3 * a_elapsed,
+                               "images_per_s": B * world / a_elapsed, "per_rank_s": a_per_rank, "gathered_records": int(pred.numel()),
+                               "asr": metrics["asr"], "psnr": metrics["psnr"], "ssim": metrics["ssim"]}
+
+    collective = None
+    if world > 1:
+        # proof that the collective backend saw every rank: a sum of ones over the process group, on the device for RCCL
+        ones = torch.ones(1, dtype=torch.int32, device=cdev)
+        dist.all_reduce(ones)
+        collective = {"backend": "rccl (torch.distributed nccl)" if backend == "nccl" else backend, "ranks_seen": int(ones.item()),
+                      "per_rank_elapsed_s": per_rank}
+        assert collective["ranks_seen"] == world, collective
 
     line = {
         "metric": "shadow-images/sec @256x256 50-step DDIM",
@@ -348,7 +432,14 @@ def main():
         "config": dict({"workload": workload, "batch_per_gpu": B, "image_size": S, "ddim_steps": args.ddim_steps,
                         "parallelism": f"batch-shard x{world}"}, **extra_cfg),
     }
-    if rank == 0 and not args.no_roofline:
+    if collective is not None:
+        line["rccl_ranks"] = collective["ranks_seen"]
+        line["collective"] = collective
+    if pipeline_attack is not None:
+        line["pipeline_attack"] = pipeline_attack
+    if stub:
+        line["data"] = "stub (ADVS_BENCH_STUB=1: host stand-ins for the GPU body; control path only)"
+    if rank == 0 and not args.no_roofline and not stub:
         eng = net.engine(B, S)
         tot = conv_profile(eng)
         c = tot["advs_conv2d"]
@@ -357,7 +448,7 @@ def main():
         alg = c[2] / (c[1] * 1e-3) / 1e12                       # the reference layers' FLOPs / time
         tr = conv_traffic_from_profiles()
         peak = PEAK_MFMA_TFLOPS[args.dtype]
-        line["roofline"] = {"bound": "mfma", "kernel": "advs_conv2d (conv3x3_halo_kernel + conv_igemm_kernel)",
+        line["roofline"] = {"bound": "mfma", "kernel": "advs_conv2d (conv3x3_halo2_kernel + conv3x3_halo_kernel + conv_igemm_kernel)",
                             "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                             "algorithmic_tflops": alg, "algorithmic_frac": alg / peak,
                             "note": "achieved/frac count EXECUTED MACs (the three sub-pixel Upsample convs run 4 of the "
@@ -370,10 +461,10 @@ def main():
                             "executed_gflop_per_launch": c[4] / c[0] / 1e9,
                             "forward_ms_by_kernel": {k: round(v[1], 3) for k, v in sorted(tot.items())},
                             "forward_ms_total": round(fwd_ms, 3)}
-    if rank == 0 and world == 1 and not attack_mode and args.dtype != "fp32" and not args.no_fp32_line:
+    if rank == 0 and world == 1 and not attack_mode and args.dtype != "fp32" and not args.no_fp32_line and not stub:
         # the exact-f32 mode (v_mfma_f32_32x32x2_f32) the <=1e-3 parity statement is made for, same workload
         net32 = build("fp32")
-        e32, _ = timed(lambda: ddim_pass(net32), 1, 1)
+        e32, _, _ = timed(lambda: ddim_pass(net32), 1, 1)
         tot32 = conv_profile(net32.engine(B, S), reps=1)
         c32 = tot32["advs_conv2d"]
         ach32 = c32[4] / (c32[1] * 1e-3) / 1e12
@@ -381,7 +472,7 @@ def main():
                                     "conv_tflops": ach32, "peak": PEAK_MFMA_TFLOPS["fp32"], "frac": ach32 / PEAK_MFMA_TFLOPS["fp32"],
                                     "forward_ms_total": round(sum(t[1] for t in tot32.values()), 3)}
         del net32
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not stub:
         line["cpu_baseline"] = cpu_baseline(S, args.ddim_steps)
     if rank == 0:
         print(json.dumps(line), flush=True)

@@ -216,6 +216,130 @@ def unet_forward(sd, hp, x, t, taps=None):
     return F.conv2d(h, sd["out.2.weight"], sd["out.2.bias"], padding=1)
 
 
+# --------------------------------------------------------------------------- forward with 16-bit STORAGE (round 3)
+def _stored_gn(sd, p, x, R, act):
+    """GroupNorm(32) [+ SiLU] of a STORED tensor, stored again: statistics of the rounded values (the conv epilogues sum what
+    they store), coefficient arithmetic of csrc/groupnorm.hip (scale = rstd * gamma, shift = beta - mean * scale, y = x * scale +
+    shift in f32), one rounding of the result."""
+    B, C, H, W = x.shape
+    xg = x.double().reshape(B, 32, -1)
+    mean = xg.mean(-1)
+    var = ((xg * xg).mean(-1) - mean * mean).clamp_min(0.0)
+    rstd = (1.0 / torch.sqrt(var + 1e-5)).float()
+    cpg = C // 32
+    scale = rstd.repeat_interleave(cpg, 1) * sd[p + ".weight"][None]
+    shift = sd[p + ".bias"][None] - mean.float().repeat_interleave(cpg, 1) * scale
+    v = x * scale[:, :, None, None] + shift[:, :, None, None]
+    return R(v * torch.sigmoid(v)) if act else R(v)
+
+
+def _stored_subpixel_upsample(x, w, bias, R, conv2d=F.conv2d):
+    """Upsample (nearest x2, then 3x3; diff_model.py:129-140) the way the plan runs it on maps that are multiples of 16: per
+    output parity (a, b) a 2x2 conv of the LOW-resolution input whose weights are the coinciding taps summed in f32 and rounded
+    ONCE (engine.pack_subpixel_upsample_weight)."""
+    B, C, H, W = x.shape
+    rows = (torch.stack([w[:, :, 0], w[:, :, 1] + w[:, :, 2]], 2), torch.stack([w[:, :, 0] + w[:, :, 1], w[:, :, 2]], 2))
+    xp = F.pad(x, (1, 1, 1, 1))
+    out = torch.empty(B, w.shape[0], 2 * H, 2 * W)
+    for a in (0, 1):
+        r = rows[a]
+        for b in (0, 1):
+            k = torch.stack([r[..., 0], r[..., 1] + r[..., 2]], 3) if b == 0 else torch.stack([r[..., 0] + r[..., 1], r[..., 2]], 3)
+            out[:, :, a::2, b::2] = conv2d(xp[:, :, a:a + H + 1, b:b + W + 1], R(k))
+    return out + bias[None, :, None, None]
+
+
+@torch.no_grad()
+def unet_forward_stored(sd, hp, x, t, storage="bf16", taps=None, exact_sums=False):
+    """UNetModel.forward (diff_model.py:245-267) with fp32 ARITHMETIC and 16-bit STORAGE: every activation and weight is rounded
+    to ``storage`` exactly where the HIP plan stores it (advshadow_amd/diff_model.py: emit_unet_forward) and nowhere else --
+      * conv / Linear-as-conv weights, and the network input of the first conv; the sub-pixel Upsample weights after the tap sums;
+      * each conv's output after bias, time embedding, fused 1x1 shortcut or identity residual were added in f32;
+      * each GroupNorm (+ SiLU) output, computed from the statistics of the STORED input;
+      * attention: q * log2(e)/sqrt(d) once more (csrc/attention.hip: attn2_kernel), the probabilities as the P.V operand
+        (relative to the row maximum; the kernel's lagged maximum moves those roundings, not their size), the output;
+    time embedding, accumulations, softmax sums, the last conv's output stay f32.  What this oracle differs by from the HIP 16-bit
+    modes is therefore summation order and v_exp / v_rcp rounding only: a comparison against it separates 16-bit ROUNDING (shared)
+    from a kernel bug (not shared), which the comparison against the fp32 oracle cannot.
+    ``exact_sums``: the convolutions and the attention products accumulate in f64 (then one rounding to f32, then the storage
+    rounding) -- same rounding POINTS, another summation: the distance between the two settings is the floor below which no
+    16-bit evaluation of this network can be pinned (a random-init net amplifies single flipped roundings)."""
+    st = {"bf16": torch.bfloat16, "fp16": torch.float16}[storage]
+    R = lambda a: a.to(st).float()
+    if exact_sums:
+        def conv2d(a, w, b=None, **kw):
+            return torch.nn.functional.conv2d(a.double(), w.double(), None if b is None else b.double(), **kw).float()
+
+        def einsum(eq, a, b):
+            return torch.einsum(eq, a.double(), b.double()).float()
+    else:
+        conv2d, einsum = torch.nn.functional.conv2d, torch.einsum
+    heads = hp["num_heads"]
+    emb = timestep_embedding(t, hp["model_channels"])
+    emb = F.linear(emb, sd["time_embed.0.weight"], sd["time_embed.0.bias"])
+    emb = F.linear(F.silu(emb), sd["time_embed.2.weight"], sd["time_embed.2.bias"])
+
+    def res(p, x):
+        a1 = _stored_gn(sd, p + ".conv1.0", x, R, True)
+        te = F.linear(F.silu(emb), sd[p + ".time_emb.1.weight"], sd[p + ".time_emb.1.bias"])
+        h = R(conv2d(a1, R(sd[p + ".conv1.2.weight"]), sd[p + ".conv1.2.bias"], padding=1) + te[:, :, None, None])
+        a2 = _stored_gn(sd, p + ".conv2.0", h, R, True)
+        y = conv2d(a2, R(sd[p + ".conv2.3.weight"]), sd[p + ".conv2.3.bias"], padding=1)
+        if p + ".shortcut.weight" in sd:
+            return R(y + conv2d(x, R(sd[p + ".shortcut.weight"]), sd[p + ".shortcut.bias"]))
+        return R(y + x)
+
+    def attn(p, x):
+        B, C, H, W = x.shape
+        n = _stored_gn(sd, p + ".norm", x, R, False)
+        qkv = R(conv2d(n, R(sd[p + ".qkv.weight"])))
+        q, k, v = qkv.reshape(B * heads, -1, H * W).chunk(3, dim=1)
+        d = C // heads
+        qs = R(q * (math.log2(math.e) / math.sqrt(d)))
+        s = einsum("bct,bcs->bts", qs, k)                             # log2-domain scores
+        pr = torch.exp2(s - s.max(dim=-1, keepdim=True).values)
+        o = einsum("bts,bcs->bct", R(pr), v) / pr.sum(-1)[:, None, :]
+        o = R(o).reshape(B, -1, H, W)
+        return R(conv2d(o, R(sd[p + ".proj.weight"]), sd[p + ".proj.bias"]) + x)
+
+    def layer(l, h):
+        kind, p, _, _ = l
+        if kind == "conv":
+            return R(conv2d(R(h), R(sd[p + ".weight"]), sd[p + ".bias"], padding=1))
+        if kind == "res":
+            return res(p, h)
+        if kind == "attn":
+            return attn(p, h)
+        if kind == "down":
+            return R(conv2d(h, R(sd[p + ".op.weight"]), sd[p + ".op.bias"], stride=2, padding=1))
+        if kind == "up":
+            if h.shape[2] % 16 == 0 and h.shape[3] % 16 == 0:
+                return R(_stored_subpixel_upsample(h, sd[p + ".conv.weight"], sd[p + ".conv.bias"], R, conv2d))
+            return R(conv2d(F.interpolate(h, scale_factor=2, mode="nearest"), R(sd[p + ".conv.weight"]), sd[p + ".conv.bias"], padding=1))
+        raise ValueError(kind)
+
+    down, middle, up = topology(hp)
+    hs, h = [], x
+    for stg in down:
+        for l in stg:
+            h = layer(l, h)
+            if taps is not None:
+                taps[l[1]] = h
+        hs.append(h)
+    for l in middle:
+        h = layer(l, h)
+        if taps is not None:
+            taps[l[1]] = h
+    for stg in up:
+        h = torch.cat([h, hs.pop()], dim=1)
+        for l in stg:
+            h = layer(l, h)
+            if taps is not None:
+                taps[l[1]] = h
+    a = _stored_gn(sd, "out.0", h, R, True)
+    return conv2d(a, R(sd["out.2.weight"]), sd["out.2.bias"], padding=1)
+
+
 # --------------------------------------------------------------------------- schedules / sampler
 def betas_linear(T):
     """diff_model.py:269-273 (float64)."""

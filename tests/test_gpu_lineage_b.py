@@ -150,6 +150,32 @@ def test_p_sample_step_and_device_noise():
     assert xt.shape == x.shape
 
 
+@pytest.mark.parametrize("clip", [True, False])
+def test_p_mean_variance_mixed_timesteps_vs_oracle(clip):
+    """p_mean_variance (diff_model.py:373-383) with a DIFFERENT timestep per image (runs of equal t share a launch) and both
+    settings of clip_denoised, against the oracle's restatement of the same three lines; out-of-range timesteps raise like the
+    reference's gather."""
+    from advshadow_amd.diff_model import GaussianDiffusion
+    net = make("small")
+    gd = GaussianDiffusion(timesteps=16)
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(4, 3, 32, 32, generator=g) * 1.5
+    t = torch.tensor([15, 15, 0, 7])
+    mean, var, logvar = gd.p_mean_variance(net, x.cuda(), t.cuda(), clip_denoised=clip)
+    tb = ob.posterior_tables(16, "cosine")
+    ex = lambda a: a.gather(0, t).float().reshape(-1, 1, 1, 1)
+    eps = net(x.cuda(), t.cuda()).cpu()
+    x0 = ex(tb["sqrt_recip"]) * x - ex(tb["sqrt_recipm1"]) * eps
+    if clip:
+        x0 = x0.clamp(-1.0, 1.0)
+    ref = ex(tb["c1"]) * x0 + ex(tb["c2"]) * x
+    assert (mean.cpu() - ref).abs().max().item() < 1e-5
+    assert torch.allclose(logvar.cpu().view(-1), tb["logvar"].gather(0, t).float()) and var.shape == (4, 1, 1, 1)
+    for bad in ([16, 0, 0, 0], [0, -1, 0, 0]):
+        with pytest.raises(IndexError):
+            gd.p_mean_variance(net, x.cuda(), torch.tensor(bad).cuda())
+
+
 def test_full_size_properties_bf16():
     """BASELINE config 1 at full size (batch 32, 256x256, bf16, default UNetModel; 4 DDIM steps keep it short):
     size-independent properties -- replays are bit-identical, outputs are finite and bounded, and an image's trajectory
@@ -225,26 +251,49 @@ def _teacher_forced_256():
     return cases
 
 
-# measured on MI355X (round 2): bf16 max 0.015 / 0.175 / 0.020 at t = 981 / 501 / 21, mean 0.0022-0.0027; fp16 max 0.0024 /
-# 0.0199 / 0.0023, mean 0.00026-0.00034 (the t = 501 maxima are isolated pixels; the means do not move)
+# Against the fp32 oracle (measured on MI355X, round 2): bf16 max 0.015 / 0.175 / 0.020 at t = 981 / 501 / 21, mean 0.0022-0.0027;
+# fp16 max 0.0024 / 0.0199 / 0.0023, mean 0.00026-0.00034 -- the t = 501 maxima are isolated pixels, ten times the others.  Round 3
+# pins what that is with the STORED oracle (oracle.lineage_b.unet_forward_stored: fp32 arithmetic, activations and weights rounded
+# to the storage type exactly where the plan stores them):
+#   * stored vs fp32 oracle, pure CPU: max 0.0157 / 0.155 / 0.021, mean ~0.002 -- the t = 501 spike is there WITHOUT any HIP kernel:
+#     it is 16-bit rounding amplified by the random-init network, not a kernel's doing;
+#   * the same stored oracle with its sums taken in f64 instead of f32 (same rounding points, another summation order) moves by
+#     max ~0.011, mean ~0.0018 at 128 x 128: a single flipped rounding is amplified to the full 16-bit error level, so NO
+#     evaluation of this network in 16-bit storage can be pinned below that floor -- the 0.03 / 5e-4 a stored oracle would
+#     ordinarily allow does not exist here;
+#   * the gate is therefore relative: the HIP 16-bit eps must be as close to the stored oracle as the stored oracle's two
+#     summation orders are to each other (mean within 1.3x, max within 2x of that floor, measured on the same input), and inside
+#     the old absolute envelope against the fp32 oracle.
 @pytest.mark.parametrize("dt,emax,emean", [("bf16", 0.25, 0.004), ("fp16", 0.03, 0.0005)])
 def test_teacher_forced_16bit_at_256_vs_oracle(dt, emax, emean):
-    """The headline dtype at the headline SHAPE against the oracle: default UNetModel, 2x3x256x256, inputs taken from the
-    fp32 trajectory of the 50-step sequence [981, 961, ..., 1] (teacher forcing: random-init nets amplify 16-bit error
-    over a free-running loop) at an early, a middle and a late step.  Per forward: the fp32 HIP eps
-    within 1e-4 of the CPU oracle, the 16-bit eps within (emax, emean) of it -- every level-0 shape of the halo kernel
-    (M = 65 536 per image, K = 1152 / 2304 / 3456, fused shortcut, sub-pixel upsample) in the dtype the bench runs."""
+    """The headline dtype at the headline SHAPE: default UNetModel, 2x3x256x256, inputs taken from the fp32 trajectory of the
+    50-step sequence [981, 961, ..., 1] (teacher forcing: random-init nets amplify 16-bit error over a free-running loop,
+    BASELINE.md sec. 2) at an early, a middle and a late step.  Per forward: the fp32 HIP eps within 1e-4 of the CPU oracle; the
+    16-bit eps against the STORED oracle of the same storage type within the floor that oracle's own summation order sets
+    (see above), and within (emax, emean) of the fp32 oracle -- every level-0 shape of the halo kernels (M = 65 536 per image,
+    K = 1152 / 2304 / 3456, GroupNorm on load, fused shortcut, sub-pixel upsample) in the dtype the bench runs."""
     cases = _teacher_forced_256()
+    hp = ob.hparams()
+    sd = ob.init_state_dict(0, hp)
     torch.manual_seed(0)
     net16 = UNetModel(compute_dtype=dt).to("cuda").eval()
-    worst = []
+    rows = []
     for x_in, t, ref in cases:
         tt = torch.full((2,), t, dtype=torch.long, device="cuda")
         for _ in range(2):                                  # second call replays the captured graph
-            err = (net16(x_in.cuda(), tt).cpu() - ref).abs()
-        worst.append((t, round(err.max().item(), 5), round(err.mean().item(), 6)))
-    print("teacher-forced 256", dt, worst)
-    assert all(m < emax and a < emean for _, m, a in worst), worst
+            got = net16(x_in.cuda(), tt).cpu()
+        tc = torch.full((2,), t, dtype=torch.long)
+        stored = ob.unet_forward_stored(sd, hp, x_in, tc, storage=dt)
+        floor = (ob.unet_forward_stored(sd, hp, x_in[:1], tc[:1], storage=dt, exact_sums=True) - stored[:1]).abs()    # image 0
+        es, ef, eo = (got - stored).abs(), (got - ref).abs(), (stored - ref).abs()
+        rows.append(dict(t=t, hip_vs_stored=(es.max().item(), es.mean().item()), hip_vs_stored_img0=(es[:1].max().item(), es[:1].mean().item()),
+                         floor_img0=(floor.max().item(), floor.mean().item()), hip_vs_fp32=(ef.max().item(), ef.mean().item()),
+                         stored_vs_fp32=(eo.max().item(), eo.mean().item())))
+    print("teacher-forced 256", dt, rows)
+    for r in rows:
+        assert r["hip_vs_stored_img0"][1] < 1.3 * r["floor_img0"][1], r          # as close as two valid 16-bit evaluations are to each other
+        assert r["hip_vs_stored_img0"][0] < 2.0 * max(r["floor_img0"][0], r["stored_vs_fp32"][0]), r
+        assert r["hip_vs_fp32"][0] < emax and r["hip_vs_fp32"][1] < emean, r
 
 
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
@@ -268,3 +317,18 @@ def test_norm_inside_conv_is_bit_identical_to_two_passes(dt):
         del net, eng
         torch.cuda.empty_cache()
     assert torch.equal(outs[0], outs[1]), (outs[0] - outs[1]).abs().max().item()
+
+
+def test_every_conv_launch_of_the_headline_forward_is_bit_reproducible():
+    """tools/determinism_check.py --convs-only --reps 3 as a test: every advs_conv2d launch of the headline plan
+    (default UNetModel, 32 x 3 x 256 x 256, bf16: halo kernels of both generations with GroupNorm-on-load, fused shortcut,
+    sub-pixel upsample, strided igemm) is rerun three times on identical inputs; y and the epilogue's GroupNorm statistics must
+    not differ by one byte.  This is the check that caught the packed-f32 statistics bug in round 2."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "determinism_check", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "determinism_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main(["--convs-only", "--reps", "3"]) == 0
+    torch.cuda.empty_cache()

@@ -229,6 +229,8 @@ ATT_CASES = [
     # B, N, heads, d, layout
     (2, 64, 4, 64, "b"), (1, 256, 4, 32, "b"), (1, 1024, 4, 64, "b"), (2, 64, 2, 96, "b"),
     (1, 256, 2, 128, "b"), (1, 1024, 2, 32, "b"), (2, 256, 4, 16, "a"), (1, 64, 4, 64, "a"),
+    # head widths that are not multiples of 32: zero-padded K chunk + ones row (24), ones row in the SECOND V^T tile (40, 48, 56)
+    (1, 256, 2, 24, "b"), (2, 196, 3, 48, "a"), (1, 144, 2, 40, "b"), (1, 324, 1, 56, "a"),
 ]
 
 

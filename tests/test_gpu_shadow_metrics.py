@@ -64,6 +64,22 @@ def test_external_contours_vs_suzuki_oracle_and_scipy(name):
     assert batch[0] == got and batch[1] == [] and len(batch[2]) == len(got)
 
 
+def test_external_contours_more_than_the_first_buffer_holds():
+    """A speckled mask (JPEG noise around a threshold) has more external contours than the first output buffer (4096): the host
+    runs the kernel again with room for all of them, as cv2.findContours simply returns them all.  Boxes and the
+    count against scipy.ndimage; every speckle is one pixel: area 0, 1 x 1 box, raster-last first."""
+    from scipy import ndimage as ndi
+    m = np.zeros((200, 200), np.uint8)
+    m[::2, ::2] = 255                                     # 10 000 isolated pixels (8-connectivity keeps them apart)
+    m[101:140, 31:90] = 255                               # and one blob that swallows a few of them
+    got = shadow.external_contours(Image.fromarray(m))
+    lab, n = ndi.label(m != 0, structure=np.ones((3, 3)))
+    assert n > shadow.MAX_CONTOURS and len(got) == n
+    boxes = sorted((sl[1].start, sl[0].start, sl[1].stop - sl[1].start, sl[0].stop - sl[0].start) for sl in ndi.find_objects(lab))
+    assert sorted(c[:4] for c in got) == boxes
+    assert got[0][:5] == (198, 198, 1, 1, 0) and [c[5] for c in got] == sorted((c[5] for c in got), reverse=True)
+
+
 @pytest.mark.parametrize("size", [(64, 64), (97, 131), (256, 256)])
 def test_add_shadow_bit_exact_vs_pillow(size):
     img, hard, soft = synth(*size, seed=1)

@@ -31,6 +31,34 @@ def test_library_exports_every_declared_symbol():
     assert lib.advs_abi_version() == 1
 
 
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+def test_no_packed_f32_arithmetic_in_the_shipped_code_objects(tmp_path):
+    """Round 2 traced run-to-run differences of the GroupNorm sums to `v_pk_add_f32 ... op_sel:[0,1] op_sel_hi:[1,0]` beside MFMA
+    waves (tools/probe_pk.hip) and the library is built with `-target-feature -packed-fp32-ops`.  This fails the moment a flag or
+    toolchain change brings any v_pk_{add,mul,fma}_f32 back into a gfx950 code object of libadvshadow_hip.so.  It also pins
+    what the library is: gfx950 only, MFMA instructions present, no getenv in the product build."""
+    import shutil
+    import subprocess
+    if not os.path.exists(OBJDUMP):
+        pytest.skip("llvm-objdump of the ROCm toolchain not present")
+    so = tmp_path / "lib.so"                        # --offloading writes the bundles next to its input
+    shutil.copy(_lib.LIB_PATH, so)
+    subprocess.run([OBJDUMP, "--offloading", str(so)], check=True, capture_output=True, cwd=tmp_path)
+    bundles = sorted(f for f in os.listdir(tmp_path) if "amdgcn" in f)
+    assert bundles and all(f.endswith("gfx950") for f in bundles), bundles
+    packed, mfma = [], 0
+    for f in bundles:
+        asm = subprocess.run([OBJDUMP, "-d", str(tmp_path / f)], check=True, capture_output=True, text=True).stdout
+        packed += [ln.strip() for ln in asm.splitlines() if re.search(r"\bv_pk_(add|mul|fma)_f32\b", ln)]
+        mfma += len(re.findall(r"\bv_mfma_f32_", asm))
+    assert not packed, packed[:5]
+    assert mfma > 1000
+    syms = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    assert "getenv" not in syms, "the product build reads no environment variable (A/B knobs live behind make DIAG=1)"
+
+
 def test_missing_gpu_fails_loudly():
     if torch.cuda.is_available():
         pytest.skip("GPU present")

@@ -95,11 +95,58 @@ def test_bench_self_launch_two_ranks(tmp_path, capsys):
 
 
 def test_bench_self_launch_propagates_failure(tmp_path):
+    """Rank 1 dies before the rendezvous; rank 0 then sits in init_process_group with the DEFAULT (30 min) timeout.  The parent
+    polls every child, so it must end the run with rank 1's code within seconds and take rank 0 down itself."""
+    import time
     import bench
     stub = tmp_path / "stub.py"
-    stub.write_text(_STUB.replace('dist.init_process_group("gloo", rank=rank, world_size=world)',
-                                  'dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=20))'))
-    assert bench.self_launch(2, ["--fail"], script=str(stub)) != 0
+    stub.write_text(_STUB)
+    t0 = time.time()
+    assert bench.self_launch(2, ["--fail"], script=str(stub)) == 3
+    assert time.time() - t0 < 60
+
+
+def _run_bench_stub(extra, launcher=False, ranks=2):
+    """bench.py's REAL control path at N = 2 on the CPU: ADVS_BENCH_BACKEND=gloo, ADVS_BENCH_STUB=1 (host stand-ins for the
+    sampler and the attack shard; rendezvous, barriers, max-over-ranks timing, gather and JSON are the shipped code)."""
+    import json
+    import subprocess
+    env = dict(os.environ, ADVS_BENCH_BACKEND="gloo", ADVS_BENCH_STUB="1", ADVS_BENCH_PG_TIMEOUT_S="60")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    bench_py = os.path.join(ROOT, "bench.py")
+    args = ["--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--batch", "5"] + extra
+    if launcher:                              # the driver's N > 1 command form
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
+               "--master-port", str(29700 + os.getpid() % 200), bench_py] + args
+    else:                                     # ... and the launcher-less form (bench.py starts its own ranks)
+        cmd = [sys.executable, bench_py] + args
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.lstrip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("launcher", [False, True])
+def test_bench_two_rank_control_path_gloo(launcher):
+    line = _run_bench_stub([], launcher=launcher)
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert line["rccl_ranks"] == 2 and line["collective"]["ranks_seen"] == 2 and line["collective"]["backend"] == "gloo"
+    per = line["collective"]["per_rank_elapsed_s"]
+    assert len(per) == 2 and abs(max(per) * 1e3 / 2 - line["ms_per_step"]) < 1e-6          # MAX over ranks is what is reported
+    assert line["ms_per_step"] >= 20.0                                                        # rank 1 sleeps 20 ms per pass
+    assert abs(line["value"] - 2 * 5 * 2 / (line["ms_per_step"] * 2e-3)) < 1e-6              # whole-job images / time
+    pa = line["pipeline_attack"]                                                              # config 3's loop rides along at N > 1
+    assert pa["images"] == 10 and pa["gathered_records"] == 10 and 0.0 <= pa["asr"] <= 1.0 and len(pa["per_rank_s"]) == 2
+    assert "roofline" not in line and "cpu_baseline" not in line                              # rank-0, N = 1 objects only
+
+
+def test_bench_two_rank_attack_pipeline_gloo():
+    line = _run_bench_stub(["--pipeline", "attack"])
+    cfg = line["config"]
+    assert cfg["pipeline"] == "attack" and line["rccl_ranks"] == 2 and "pipeline_attack" not in line
+    assert cfg["asr"] == 0.0 and abs(cfg["psnr"] - (10.0 + 4.5)) < 1e-6                       # the stub's records, gathered in global order
 
 
 def test_bench_rejects_mismatched_world(monkeypatch):

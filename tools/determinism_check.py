@@ -46,7 +46,8 @@ def outputs(fn, args, esz):
     return []
 
 
-def main():
+def main(argv=None):
+    """Returns the number of launches whose rerun differed (0 = every launch bit-reproducible)."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--size", type=int, default=256)
@@ -54,7 +55,7 @@ def main():
     ap.add_argument("--reps", type=int, default=1, help="reruns of every launch compared with its first run")
     ap.add_argument("--convs-only", action="store_true")
     ap.add_argument("--lib", default=None, help="load this build of libadvshadow_hip.so instead of the in-tree one (A/B diagnostics)")
-    a = ap.parse_args()
+    a = ap.parse_args(argv)
     if a.lib:
         from advshadow_amd import _lib
         _lib.LIB_PATH = os.path.abspath(a.lib)
@@ -98,7 +99,8 @@ def main():
                     bad += 1
                     break
     print("nondeterministic launches:", bad, "of", len(eng.plan.ops))
+    return bad
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(1 if main() else 0)
