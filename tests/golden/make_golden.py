@@ -220,7 +220,41 @@ def gen_cspdark():
     run("lrelu", 4, "lrelu", False)
 
 
-GROUPS = {"lineage_b": gen_lineage_b, "lineage_a": gen_lineage_a, "samplers": gen_samplers, "cspdark": gen_cspdark}
+# --------------------------------------------------------------------------- the reference's REAL widths + the 'quad' sequence (round 3)
+def gen_wide():
+    """The hyper-parameters the reference's drivers actually instantiate: ddim2/main2.py:118-127
+    (six levels (1,1,2,2,4,4), attention at ds 4/8/16/32, 121.5 M parameters, 128-channel heads at 512 channels) and gen.py:522-528
+    "cs2" ((1,2,3,4), attention at ds 2, 81.3 M) -- one forward each at 64x64, outputs only -- and ddim_sample's
+    ddim_discr_method='quad' branch (diff_model.py:431-434) on the small net."""
+    import diff_model as dm
+    dm.tqdm = lambda it, **k: it
+    arrs = {}
+    for tag, seed, hp in (("ddim2", 11, dict(num_res_blocks=2, attention_resolutions=(4, 8, 16, 32), channel_mult=(1, 1, 2, 2, 4, 4), dropout=0.1)),
+                          ("cs2", 12, dict(num_res_blocks=2, channel_mult=(1, 2, 3, 4), attention_resolutions=(2,), dropout=0.1))):
+        torch.manual_seed(seed)
+        net = dm.UNetModel(**hp).eval()
+        keys, dg = digest(net.state_dict())
+        arrs[f"{tag}_sd_keys"], arrs[f"{tag}_sd_digest"] = keys, dg
+        arrs[f"{tag}_nparams"] = np.array(sum(p.numel() for p in net.parameters()))
+        g = torch.Generator().manual_seed(1000 + seed)
+        x = torch.randn(1, 3, 64, 64, generator=g)
+        arrs[f"{tag}_x"] = x.numpy()
+        with torch.no_grad():
+            for t in (21, 801):
+                arrs[f"{tag}_eps_t{t}"] = net(x, torch.full((1,), t, dtype=torch.long)).numpy()
+    small = dict(model_channels=64, channel_mult=(1, 2), num_res_blocks=1, attention_resolutions=(2,), num_heads=4)
+    torch.manual_seed(3)
+    net = dm.UNetModel(**small).eval()
+    gd = dm.GaussianDiffusion()
+    torch.manual_seed(1234)
+    arrs["quad_xT"] = torch.randn((2, 3, 32, 32)).numpy()
+    torch.manual_seed(1234)
+    arrs["quad_out"] = gd.ddim_sample(net, 32, batch_size=2, channels=3, ddim_timesteps=7, ddim_discr_method="quad")
+    arrs["quad_seq"] = ((np.linspace(0, np.sqrt(1000 * .8), 7)) ** 2).astype(int) + 1
+    save("lineage_b_wide.npz", **arrs)
+
+
+GROUPS = {"wide": gen_wide, "lineage_b": gen_lineage_b, "lineage_a": gen_lineage_a, "samplers": gen_samplers, "cspdark": gen_cspdark}
 
 if __name__ == "__main__":
     for g in (sys.argv[1:] or list(GROUPS)):

@@ -168,3 +168,77 @@ def test_config4_reduced_fp16_ddim100_vit_victim():
         worst = max(worst, (e16 - eps32).abs().max().item())
     print("config-4 reduced: fp16 vs fp32 eps along the 100-step trajectory, max", worst)
     assert worst < 0.02
+
+
+def test_config2_full_size_attack_loop():
+    """BASELINE config 2 at FULL size on one GPU: batch 64, 3x256x256, bf16 default UNetModel (4 DDIM steps keep it short) ->
+    uint8 -> Pillow-exact resize 224 -> ResNet-50 victim -> argmax; apply_shadow closed form -> 64x64 -> PSNR/SSIM.  For ALL 64
+    images: the fp32 victim plan takes the CPU oracle's top-1 decision (oracle/victims.resnet50_forward on the SAME uint8
+    images, ASR_fast.py:90-97 preprocessing), the bf16 victim plan wherever the oracle's top-1 margin exceeds twice the bf16
+    logit error; PSNR / SSIM equal oracle/metrics on oracle/shadow's composite; and the two shards of 32 that a 2-GPU run would
+    hold (x_T drawn per GLOBAL image id) reproduce images, decisions and metrics bit for bit (ASR_fast.py:101-126,
+    PSNR_SSIM_fast.py:21-56)."""
+    from advshadow_amd import _lib
+    from advshadow_amd.asr import evaluate_batch
+    n, S, steps = 64, 256, 4
+    torch.manual_seed(0)
+    net = UNetModel(compute_dtype="bf16").to("cuda").eval()
+    gd = GaussianDiffusion()
+    torch.manual_seed(1)
+    v32 = ResNet50(37)
+    vsd = ov.randomize_bn({k: v.clone() for k, v in v32.state_dict().items()}, 9)
+    v32.load_state_dict(vsd)
+    v32 = v32.to("cuda").eval()
+    v16 = ResNet50(37, compute_dtype="bf16")
+    v16.load_state_dict(vsd)
+    v16 = v16.to("cuda").eval()
+    g = torch.Generator().manual_seed(7)
+    clean = torch.rand(n, 3, S, S, generator=g)
+    yy, xx = torch.meshgrid(torch.arange(S), torch.arange(S), indexing="ij")
+    fm1 = (((xx - 128.0) ** 2 + (yy - 128.0) ** 2) <= 80.0 ** 2).float()
+    fmask = fm1[None, None].expand(n, 1, S, S).contiguous()
+    centers, radii = torch.tensor([[128.0, 128.0]] * n), torch.tensor([40.0] * n)
+
+    def shard(lo, hi, victim):
+        xT = parallel.image_noise(range(lo, hi), (3, S, S)).cuda()
+
+        def sample_fn():
+            x = gd.ddim_sample(net, S, batch_size=hi - lo, ddim_timesteps=steps, x_T=xT, return_tensor=True)
+            out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+            _lib.check(_lib.load().advs_to_uint8(x.data_ptr(), out.data_ptr(), x.numel(), 1, torch.cuda.current_stream().cuda_stream))
+            return out
+        return attack.attack_shard(sample_fn, victim, clean[lo:hi].cuda(), fmask[lo:hi].cuda(), centers[lo:hi], radii[lo:hi])
+
+    gen, pred16, psnr, ssim = shard(0, n, v16)
+    assert gen.shape == (n, 3, S, S) and gen.dtype == torch.uint8 and pred16.shape == (n,)
+    # ---- shard invariance: 64 = 2 x 32
+    for lo in (0, 32):
+        g2, p2, q2, s2 = shard(lo, lo + 32, v16)
+        sl = slice(lo, lo + 32)
+        assert torch.equal(g2, gen[sl]) and torch.equal(p2, pred16[sl]) and torch.equal(q2, psnr[sl]) and torch.equal(s2, ssim[sl])
+    # ---- decisions against the CPU oracle on the same uint8 images
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    xs = []
+    for i in range(n):
+        pil = Image.fromarray(gen[i].cpu().numpy().transpose(1, 2, 0)).resize((224, 224), Image.BILINEAR)
+        xs.append(torch.from_numpy(np.asarray(pil).transpose(2, 0, 1).astype(np.float32) / 255.0))
+    with torch.no_grad():
+        ref = torch.cat([ov.resnet50_forward(vsd, torch.stack(xs[i:i + 16])) for i in range(0, n, 16)])
+    pred32 = evaluate_batch(gen, v32)
+    assert torch.equal(pred32.cpu().long(), ref.argmax(1))                                   # all 64, fp32 plan
+    top2 = ref.topk(2, 1).values
+    margin = top2[:, 0] - top2[:, 1]
+    sure = margin > 2 * 0.01 * max(1.0, ref.abs().max().item())
+    assert int(sure.sum()) >= n // 2, margin
+    assert torch.equal(pred16.cpu().long()[sure], ref.argmax(1)[sure]), (pred16, ref.argmax(1), margin)
+    # ---- PSNR / SSIM of all 64 against the CPU restatements
+    to64 = lambda t: np.asarray(Image.fromarray((t * 255).clamp(0, 255).byte().numpy().transpose(1, 2, 0))
+                                .resize((64, 64), Image.BILINEAR)).transpose(2, 0, 1).astype(np.float32) / 255.0
+    for i in range(n):
+        sh = osh.apply_shadow(clean[i], (128.0, 128.0), 40.0, fmask[i], 0.43, 5)
+        s, p = om.calculate_ssim_psnr(to64(clean[i]), to64(sh), 7)
+        assert abs(float(ssim[i]) - s) < 1e-5 and abs(float(psnr[i]) - p) < 1e-3, i
+    labels = torch.arange(n) % 37
+    m, _ = attack.run_attack(n, lambda lo, hi: (gen, pred16, psnr, ssim), labels=labels)
+    assert m["n"] == n and abs(m["asr"] - float((pred16.cpu().long() != labels).float().mean())) < 1e-9
+    print("config 2 full size:", m, "decisions beyond the bf16 margin:", int(sure.sum()), "of", n)

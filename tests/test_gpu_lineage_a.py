@@ -177,3 +177,32 @@ def test_forward_at_256_vs_oracle():
     e16 = (lp(x.cuda(), t.cuda(), y.cuda()).cpu() - oa.unet_forward(sd, x, t, y)).abs()
     print("lineage A 256 bf16", e16.max().item(), e16.mean().item())
     assert e16.max().item() < 0.05 and e16.mean().item() < 0.008
+
+
+def test_ddim_cfg_loop_at_256_vs_oracle(golden):
+    """A whole classifier-free-guidance DDIM loop at the HEADLINE resolution: UNet(num_classes=37,
+    image_size=256), B = 1, sample_steps = 4 -- the pairs (751, 501), (501, 251), (251, 1), (1, 0) of ddim.py:52-56 -- eight
+    forwards with sa6 at N = 65 536 tokens, the fused lerp + DDIM update, the captured step graph replayed, fp32: the float
+    end point within 1e-3 per pixel of the CPU oracle's loop (north_star), the uint8 image within 1 LSB on < 1 % of the pixels
+    (wrap-aware, ddim.py:97-100).  The oracle's loop takes 3.5 minutes on the box's host cores, so its result is a committed
+    fixture (tests/golden/make_oracle_fixtures.py: oracle/lineage_a.py, itself pinned by the reference's goldens at 64 x 64);
+    the state_dict digest proves the seeded weights are the fixture's."""
+    g = golden("oracle_lineage_a_256_loop.npz")
+    torch.manual_seed(1)
+    net = UNet(num_classes=37, image_size=256, device="cuda").to("cuda").eval()
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    keys = list(g["sd_keys"])
+    assert sorted(sd.keys()) == keys
+    assert np.array_equal(np.array([[float(sd[k].double().sum()), float(sd[k].double().abs().sum())] for k in keys]), g["sd_digest"])
+    xT = torch.randn(1, 3, 256, 256, generator=torch.Generator().manual_seed(int(g["xT_seed"])))
+    labels = torch.from_numpy(g["label"])
+    assert [tuple(p) for p in g["pairs"]] == [(751, 501), (501, 251), (251, 1), (1, 0)] == [tuple(p) for p in oa.time_pairs(1000, 4)]
+    ref = torch.from_numpy(g["out"])
+    diff = DDIMDiffusion(sample_steps=4, img_size=256, device="cuda")
+    got = diff.sample(net, 1, labels=labels.cuda(), cfg_scale=3, x_T=xT, return_float=True).cpu()
+    err = (got - ref).abs().max().item()
+    print("lineage A 256 4-step DDIM + CFG, fp32: max |hip - oracle| =", err)
+    assert err < 1e-3, err
+    u8 = diff.sample(net, 1, labels=labels.cuda(), cfg_scale=3, x_T=xT).cpu().numpy()
+    d = wrap_diff(u8, ((ref + 1) * 0.5 * 255).type(torch.uint8).numpy())
+    assert d.max() <= 1 and (d > 0).mean() < 0.01, (d.max(), (d > 0).mean())

@@ -150,6 +150,56 @@ def test_p_sample_step_and_device_noise():
     assert xt.shape == x.shape
 
 
+WIDE = {   # the widths the reference's drivers instantiate: ddim2/main2.py:118-127 and gen.py:522-528 ("cs2")
+    "ddim2": (11, dict(num_res_blocks=2, attention_resolutions=(4, 8, 16, 32), channel_mult=(1, 1, 2, 2, 4, 4))),
+    "cs2": (12, dict(num_res_blocks=2, channel_mult=(1, 2, 3, 4), attention_resolutions=(2,))),
+}
+
+
+@pytest.mark.parametrize("tag", list(WIDE))
+def test_real_widths_fp32_vs_golden(golden, tag):
+    """The reference's real network widths: ddim2's six levels with 512-channel stages, attention at four
+    resolutions down to a 2 x 2 map and 128-wide heads (121.5 M parameters), and cs2's 128 / 256 / 384 / 512 channels with
+    attention on 1024 tokens (81.3 M) -- one forward each at 64 x 64 against the reference's own output, eager and graph; plus
+    the 16-bit twins against it (loose: random init)."""
+    seed, over = WIDE[tag]
+    g = golden("lineage_b_wide.npz")
+    x = torch.from_numpy(g[f"{tag}_x"]).cuda()
+    torch.manual_seed(seed)
+    net = UNetModel(**over).to("cuda").eval()
+    assert sum(p.numel() for p in net.parameters()) == int(g[f"{tag}_nparams"])
+    for t in (21, 801):
+        tt = torch.full((1,), t, dtype=torch.long, device="cuda")
+        for _ in range(2):                      # second call replays the captured graph
+            eps = net(x, tt).cpu().numpy()
+            assert np.abs(eps - g[f"{tag}_eps_t{t}"]).max() < 1e-4, t
+    for dt, emax in (("bf16", 0.15), ("fp16", 0.02)):
+        torch.manual_seed(seed)
+        lp = UNetModel(compute_dtype=dt, **over).to("cuda").eval()
+        err = np.abs(lp(x, torch.full((1,), 801, dtype=torch.long, device="cuda")).cpu().numpy() - g[f"{tag}_eps_t801"])
+        print("wide", tag, dt, err.max(), err.mean())
+        assert err.max() < emax, (dt, err.max())
+        del lp
+    del net
+    torch.cuda.empty_cache()
+
+
+def test_ddim_quad_discretisation_vs_golden(golden):
+    """ddim_discr_method='quad' (diff_model.py:431-434): the sequence ((linspace(0, sqrt(0.8 T), S)) ** 2).astype(int) + 1 and a
+    7-step loop on the small net against the reference's output, <= 1e-3 per pixel."""
+    g = golden("lineage_b_wide.npz")
+    net = make("small")
+    gd = GaussianDiffusion()
+    seq, prev = gd.ddim_sequences(1000, 7, "quad")
+    assert list(seq) == list(g["quad_seq"]) and list(prev) == [0] + list(seq[:-1])
+    xT = torch.from_numpy(g["quad_xT"])
+    for _ in range(2):
+        out = gd.ddim_sample(net, 32, batch_size=2, ddim_timesteps=7, ddim_discr_method="quad", x_T=xT)
+        assert np.abs(out - g["quad_out"]).max() < 1e-3
+    with pytest.raises(NotImplementedError):
+        gd.ddim_sample(net, 32, batch_size=2, ddim_timesteps=7, ddim_discr_method="cubic", x_T=xT)
+
+
 @pytest.mark.parametrize("clip", [True, False])
 def test_p_mean_variance_mixed_timesteps_vs_oracle(clip):
     """p_mean_variance (diff_model.py:373-383) with a DIFFERENT timestep per image (runs of equal t share a launch) and both

@@ -72,3 +72,15 @@ def test_ddpm_and_plms_match_reference(golden):
     out = oa.plms_sample(fn, torch.from_numpy(g["plms_xT"]), sample_steps=8).numpy()
     d = wrap_diff(out, g["plms_uncond"])
     assert d.max() <= 1 and (d > 0).mean() < 0.01
+
+
+def test_oracle_fixture_256_loop_is_this_oracle(golden):
+    """tests/golden/oracle_lineage_a_256_loop.npz (made by make_oracle_fixtures.py, 3.5 min of this oracle) belongs to the weights
+    and step pairs this oracle builds today; the loop itself is re-run only by that script."""
+    g = golden("oracle_lineage_a_256_loop.npz")
+    sd = oa.init_state_dict(1, num_classes=37, act="silu")
+    keys = list(g["sd_keys"])
+    assert sorted(sd.keys()) == keys
+    assert np.array_equal(np.array([[float(sd[k].double().sum()), float(sd[k].double().abs().sum())] for k in keys]), g["sd_digest"])
+    assert [tuple(p) for p in g["pairs"]] == [tuple(p) for p in oa.time_pairs(1000, 4)]
+    assert g["out"].shape == (1, 3, 256, 256) and np.isfinite(g["out"]).all() and np.abs(g["out"]).max() < 1.5
