@@ -131,7 +131,7 @@ conv3x3_halo2_kernel(const ConvKP p) {
 
     // ---- staging geometry.  Halo piece q holds pixels PP*q .. PP*q+PP-1 (row-major in the halo patch); NCH consecutive lanes fill one
     // pixel's slots in order, each fetching the chunk that belongs there (slot ^ sw(x)).
-    unsigned a_pk[NAP], a_voff[NAP];                 // (pixel index << 3 | source chunk), ~0 = outside the image / the patch
+    unsigned a_pk[NAP];                              // (pixel index << 3 | source chunk), ~0 = outside the image / the patch
     unsigned b_voff[NBP];
 #pragma unroll
     for (int j = 0; j < NAP; ++j) {
@@ -142,7 +142,6 @@ conv3x3_halo2_kernel(const ConvKP p) {
         const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
         const bool inb = q < G::A_PIECES && hidx < G::A_PIX && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
         a_pk[j] = inb ? ((unsigned)((b * p.H + gy) * p.W + gx) << 3) | (unsigned)c : 0xFFFFFFFFu;
-        a_voff[j] = OOB_OFFSET;
     }
 #pragma unroll
     for (int j = 0; j < NBP; ++j) {
@@ -161,22 +160,23 @@ conv3x3_halo2_kernel(const ConvKP p) {
     const int ne1 = XT ? p.E1 / KC : 0, ne = XT ? (p.E1 + p.E2) / KC : 0;        // one-tap units of the extra operand
     const int gtaps = nunits * NT + ne;
 
-    auto set_a_voff = [&](int unit) {                // byte offsets of this lane's halo slots in `unit`'s source
-        unsigned cs = (unsigned)(unit < ncs1 ? p.LD1 : p.LD2) * 2u;
-        if (XT && unit >= nunits) cs = (unsigned)(unit - nunits < ne1 ? p.E1 : p.E2) * 2u;
-#pragma unroll
-        for (int j = 0; j < NAP; ++j)
-            a_voff[j] = a_pk[j] != 0xFFFFFFFFu ? (a_pk[j] >> 3) * cs + (a_pk[j] & 7u) * 16u : OOB_OFFSET;
+    // byte offset of this lane's halo slot in the source of the unit being staged: pixel stride a_cs (set when the source changes).
+    // Derived per issue from a_pk (3 VALU) rather than kept per piece: the registers go to the accumulators' neighbours.
+    unsigned a_cs = 0;
+    auto set_a_voff = [&](int unit) {
+        a_cs = (unsigned)(unit < ncs1 ? p.LD1 : p.LD2) * 2u;
+        if (XT && unit >= nunits) a_cs = (unsigned)(unit - nunits < ne1 ? p.E1 : p.E2) * 2u;
     };
     auto issue_A = [&](int unit, int j) {
         const int q = wave + NW * j;
         char* dst = sA + (unit & 1) * G::A_STAGE + (q < G::A_PIECES ? q : G::A_PIECES) * 1024;    // padding DMAs: scratch piece
+        const unsigned voff = a_pk[j] != 0xFFFFFFFFu ? (a_pk[j] >> 3) * a_cs + (a_pk[j] & 7u) * 16u : OOB_OFFSET;
         if (XT && unit >= nunits) {
             const int e = unit - nunits;
-            if (e < ne1) blds16(rse1, a_voff[j], (unsigned)(e * KC * 2), dst);
-            else blds16(rse2, a_voff[j], (unsigned)((e - ne1) * KC * 2), dst);
-        } else if (unit < ncs1) blds16(rs1, a_voff[j], (unsigned)(unit * KC * 2), dst);
-        else blds16(rs2, a_voff[j], (unsigned)((unit - ncs1) * KC * 2), dst);
+            if (e < ne1) blds16(rse1, voff, (unsigned)(e * KC * 2), dst);
+            else blds16(rse2, voff, (unsigned)((e - ne1) * KC * 2), dst);
+        } else if (unit < ncs1) blds16(rs1, voff, (unsigned)(unit * KC * 2), dst);
+        else blds16(rs2, voff, (unsigned)((unit - ncs1) * KC * 2), dst);
     };
     auto issue_Bg = [&](int g, unsigned woff, int j) {          // weights of global tap g: K byte offset woff, ring stage g & 3
         blds16(rsw, b_voff[j], woff, sB + (g & (G::NB - 1)) * G::B_STAGE + (wave * NBP + j) * 1024);
@@ -190,15 +190,24 @@ conv3x3_halo2_kernel(const ConvKP p) {
         issue_Bg(g3, (unsigned)(t3 * Cin + u3 * KC) * 2u, j);
     };
 
-    // NORM: half h (8 of the lane's 16 bytes = four channels) of piece j of `unit`'s halo -- this wave's own DMA, already waited
-    // for -- becomes SiLU(scale * x + shift) in place.  Branch-free, so that a tap stays one scheduling region: a lane on zero
-    // padding (outside the image) writes its zeros back, a padding piece (q >= A_PIECES) works on the scratch piece.
+    // NORM: half h (four channels) of this lane's vector of piece j of `unit`'s halo -- this wave's own DMA, already waited for --
+    // becomes SiLU(scale * x + shift) in place.  For the transform a lane always works on source chunk (lane % NCH) of pixel
+    // (lane / NCH) of the piece, whatever slot the swizzle put it in (slot = chunk ^ sw(x) = the source chunk the DMA lane
+    // fetched, a_pk & (NCH - 1)): its eight (scale, shift) pairs then depend on the unit only and live in registers (nco, loaded
+    // once per unit) instead of being read from LDS for every vector.  Branch-free, so that a tap stays one scheduling region:
+    // a lane on zero padding (outside the image) writes its zeros back, a padding piece (q >= A_PIECES) works on the scratch piece.
+    f32x4 nco[4];                                    // (scale, shift) of channels 8 * (lane % NCH) .. +7 of the unit being normalised
+    auto norm_coeffs = [&](int unit) {
+        const float* co = (const float*)(sN + (unit * KC + (lane & (G::NCH - 1)) * 8) * 8);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) nco[i] = *(const f32x4*)(co + 4 * i);
+    };
     auto norm_half = [&](int unit, int j, int h, bool on) {
         const int q = wave + NW * j;
-        char* slot = sA + (unit & 1) * G::A_STAGE + (q < G::A_PIECES ? q : G::A_PIECES) * 1024 + lane * 16 + h * 8;
+        char* slot = sA + (unit & 1) * G::A_STAGE + (q < G::A_PIECES ? q : G::A_PIECES) * 1024 + (lane / G::NCH) * G::RB
+                     + (int)(a_pk[j] & (G::NCH - 1)) * 16 + h * 8;
         const u32x2 raw = *(const u32x2*)slot;
-        const float* co = (const float*)(sN + (unit * KC + (int)(a_pk[j] & (G::NCH - 1)) * 8 + h * 4) * 8);
-        const f32x4 c0 = *(const f32x4*)co, c1 = *(const f32x4*)(co + 4);
+        const f32x4 c0 = nco[2 * h], c1 = nco[2 * h + 1];
         float f[4];
         if constexpr (std::is_same<T, BF16>::value) {
             f[0] = __uint_as_float(raw[0] << 16); f[1] = __uint_as_float(raw[0] & 0xffff0000u);
@@ -219,8 +228,9 @@ conv3x3_halo2_kernel(const ConvKP p) {
     };
 
     // ---- fragment geometry: wave (wm, wn) owns MFMA pixel tiles wm*TM .. +TM-1 (two 16-pixel strips each) and channels wn*WNC ..
-    // a_addr[i][s][ks]: byte address inside the halo image of tile i's fragment at column shift s0 + s, k-step ks, row shift 0
-    unsigned a_addr[TM][NTW][KS], b_addr[TN][KS];
+    // a_addr[i][s]: byte address inside the halo image of tile i's fragment at column shift s0 + s, k-step 0, row shift 0; k-step ks
+    // is that address ^ (32 * ks): the chunk index (2 ks + lh) ^ sw occupies bits 4.. of the in-row offset, rows are RB-aligned
+    unsigned a_addr[TM][NTW], b_addr[TN];
     {
         int g, idx;
         h2_row_map(l31, g, idx);
@@ -232,17 +242,14 @@ conv3x3_halo2_kernel(const ConvKP p) {
             for (int s = 0; s < NTW; ++s) {
                 const int hx = sx + idx + s0 + s;
                 const int sw = (hx >> G::SWS) & (G::NCH - 1);
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
-                    a_addr[i][s][ks] = (unsigned)(((sy + r0) * G::HW + hx) * G::RB + (((2 * ks + lh) ^ sw) << 4));
+                a_addr[i][s] = (unsigned)(((sy + r0) * G::HW + hx) * G::RB + ((lh ^ sw) << 4));
             }
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = wn * G::WNC + j * 32 + l31;
             const int sw = (n >> G::SWS) & (G::NCH - 1);
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) b_addr[j][ks] = (unsigned)(n * G::RB + (((2 * ks + lh) ^ sw) << 4));
+            b_addr[j] = (unsigned)(n * G::RB + ((lh ^ sw) << 4));
         }
     }
     auto row_to_m = [&](int lr) {
@@ -274,6 +281,7 @@ conv3x3_halo2_kernel(const ConvKP p) {
         for (int c = tid; c < Cin; c += G::NTHR) ((float2*)sN)[c] = tb[c];
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NBP) : "memory");
         __syncthreads();                                             // the table is visible (the weight DMAs drain here too: once per workgroup)
+        norm_coeffs(0);
 #pragma unroll
         for (int j = 0; j < NAP; ++j) { norm_half(0, j, 0, true); norm_half(0, j, 1, true); }
     }
@@ -282,12 +290,15 @@ conv3x3_halo2_kernel(const ConvKP p) {
     conv_acc_init<TM, TN>(p, acc, lane, n0 + wn * G::WNC, b);
 
     u32x4 af[2][TM], bf[2][TN];                      // [k-step parity][tile]; slot 0 is carried across taps
-    // fragments of (row shift r, column shift s, k-step ks) from halo image la and weight stage lb: registers + the immediate r * A_ROW
-    auto load_frags = [&](int slot, const char* la, const char* lb, int r, int s, int ks) {
+    // fragments of (row shift r, column shift s, k-step ks): a_addr already carries the CURRENT halo buffer's base (it is moved by
+    // +-A_STAGE at every unit boundary), `adelta` reaches the other buffer for the prefetch across a unit boundary; `boff` is the
+    // weight ring stage of the tap.  Both offsets are kept opaque to the compiler: left to itself it materialises the sums for
+    // both halo buffers and all four ring stages (~50 registers) and spills beside the 128 accumulators.
+    auto load_frags = [&](int slot, int adelta, int boff, int r, int s, int ks) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[slot][i] = *(const u32x4*)(la + a_addr[i][s][ks] + r * G::A_ROW);
+        for (int i = 0; i < TM; ++i) af[slot][i] = *(const u32x4*)(sA + ((a_addr[i][s] ^ (unsigned)(32 * ks)) + adelta) + r * G::A_ROW);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bf[slot][j] = *(const u32x4*)(lb + b_addr[j][ks]);
+        for (int j = 0; j < TN; ++j) bf[slot][j] = *(const u32x4*)(sB + ((b_addr[j] ^ (unsigned)(32 * ks)) + boff));
     };
     auto mma_step = [&](int cur) {
 #pragma unroll
@@ -300,13 +311,13 @@ conv3x3_halo2_kernel(const ConvKP p) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NBP) : "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    load_frags(0, sA, sB, 0, 0, 0);
+    load_frags(0, 0, 0, 0, 0, 0);
 
     for (int unit = 0; unit < nunits; ++unit) {
         const bool hn = unit + 1 < nunits + ne;      // a next unit exists: its halo is prefetched during this one
         if (hn && (unit + 1 == ncs1 || unit == 0 || unit + 1 == nunits || unit + 1 == nunits + ne1)) set_a_voff(unit + 1);
-        const char* la = sA + (unit & 1) * G::A_STAGE;
-        const char* la_next = sA + ((unit + 1) & 1) * G::A_STAGE;
+        int nxt_delta = (unit & 1) ? -G::A_STAGE : G::A_STAGE;   // from this unit's halo buffer to the next one's
+        asm volatile("" : "+s"(nxt_delta));
         const bool norm_on = NORM && unit + 1 < nunits;          // the next unit is a 3x3 unit: its halo is normalised in this one
         auto tap = [&](auto tc) {
             constexpr int t = decltype(tc)::value;
@@ -322,8 +333,8 @@ conv3x3_halo2_kernel(const ConvKP p) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             constexpr int r = t / NTW, s = t % NTW;                   // tap shift relative to (r0, s0), which a_addr carries
-            const char* lb = sB + (it & (G::NB - 1)) * G::B_STAGE;
-            const char* lbn = sB + ((it + 1) & (G::NB - 1)) * G::B_STAGE;
+            int lb = (it & (G::NB - 1)) * G::B_STAGE, lbn = ((it + 1) & (G::NB - 1)) * G::B_STAGE;
+            asm volatile("" : "+s"(lb), "+s"(lbn));
             // this tap's DMA issues, weights first (the counted wait assumes that order), spread towards the late k-steps; they open
             // their k-step, so that what follows (fragment reads, NORM arithmetic, MFMAs) is ONE scheduling region per k-step
             constexpr int nAt = h2_a_pieces<NT, NAP>(t), a0 = h2_a_first<NT, NAP>(t);
@@ -341,13 +352,16 @@ conv3x3_halo2_kernel(const ConvKP p) {
                     else if (hn) issue_A(unit + 1, a0 + k - NBP);
                 }
                 if (ks < KS - 1) {
-                    load_frags(nxt, la, lb, r, s, ks + 1);
+                    load_frags(nxt, 0, lb, r, s, ks + 1);
                 } else if (t < NT - 1) {                              // first fragments of the next tap, same unit
                     constexpr int rn = (t + 1) / NTW, sn = (t + 1) % NTW;
-                    load_frags(nxt, la, lbn, rn, sn, 0);
+                    load_frags(nxt, 0, lbn, rn, sn, 0);
                 } else if (hn) {                                      // ... or the first tap of the next unit's halo
-                    if (XT && unit + 1 >= nunits) load_frags(nxt, la_next, lbn, 1, 1, 0);   // an extra unit's only tap: the centre
-                    else load_frags(nxt, la_next, lbn, 0, 0, 0);
+                    if (XT && unit + 1 >= nunits) load_frags(nxt, nxt_delta, lbn, 1, 1, 0);   // an extra unit's only tap: the centre
+                    else load_frags(nxt, nxt_delta, lbn, 0, 0, 0);
+                }
+                if constexpr (NORM) {
+                    if (t == 1 && ks == 0 && norm_on) norm_coeffs(unit + 1);       // ahead of the first piece's tap (wave-uniform branch)
                 }
                 if constexpr (norm_here) {
                     if (ks < 2) norm_half(unit + 1, t - 2, ks, norm_on);
@@ -362,6 +376,10 @@ conv3x3_halo2_kernel(const ConvKP p) {
             tap(std::integral_constant<int, 4>{}); tap(std::integral_constant<int, 5>{}); tap(std::integral_constant<int, 6>{});
             tap(std::integral_constant<int, 7>{}); tap(std::integral_constant<int, 8>{});
         }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int s = 0; s < NTW; ++s) a_addr[i][s] += nxt_delta;                  // the next unit reads the other buffer
     }
     if constexpr (XT) {
         for (int e = 0; e < ne; ++e) {
@@ -372,13 +390,13 @@ conv3x3_halo2_kernel(const ConvKP p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            const char* la = sA + (unit & 1) * G::A_STAGE;
-            const char* lb = sB + (it & (G::NB - 1)) * G::B_STAGE;
-            if (e > 0) load_frags(0, la, lb, 1, 1, 0);               // unit 0's first fragments came with the last 3x3 tap
+            int lb = (it & (G::NB - 1)) * G::B_STAGE;
+            asm volatile("" : "+s"(lb));
+            if (e > 0) load_frags(0, 0, lb, 1, 1, 0);                // unit 0's first fragments came with the last 3x3 tap
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const int cur = ks & 1, nxt = cur ^ 1;
-                if (ks < KS - 1) load_frags(nxt, la, lb, 1, 1, ks + 1);
+                if (ks < KS - 1) load_frags(nxt, 0, lb, 1, 1, ks + 1);
                 if (ks == 0 && it + 3 < gtaps) {
 #pragma unroll
                     for (int j = 0; j < NBP; ++j) issue_Bg(it + 3, (unsigned)(NT * Cin + (e + 3) * KC) * 2u, j);
@@ -390,6 +408,11 @@ conv3x3_halo2_kernel(const ConvKP p) {
                 }
                 mma_step(cur);
             }
+            const int dlt = (unit & 1) ? -G::A_STAGE : G::A_STAGE;  // the next extra unit reads the other halo buffer
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int s = 0; s < NTW; ++s) a_addr[i][s] += dlt;
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // padding DMAs included: the epilogue reuses the LDS
