@@ -278,7 +278,7 @@ attn_kernel(const AttnP p) {
 //     out of the P.V product, rescaling included: no per-score add;
 //   * keys are staged SUB 64-key tiles at a time: one barrier pair per 64 * SUB keys instead of per 64.
 // Exact softmax algebra otherwise (online rescaling, masked padding keys).  FLOPs per launch: 4 * B * heads * N^2 * d.
-template <typename T, int DT, int SUB>
+template <typename T, int DT, int SUB, bool ONES>
 __global__ void __launch_bounds__(AT_THREADS, 2)
 attn2_kernel(const AttnP p) {
     constexpr int ESZ = 2;
@@ -305,7 +305,8 @@ attn2_kernel(const AttnP p) {
     const char* qp = base + (size_t)(p.q_off + hd * p.head_stride) * ESZ;
     const char* kp = base + (size_t)(p.k_off + hd * p.head_stride) * ESZ;
     const char* vp = base + (size_t)(p.v_off + hd * p.head_stride) * ESZ;
-    const bool ones_row = (d & 31) != 0;          // V^T row d of the last tile is all ones: O^T row d = the softmax denominator
+    constexpr bool ones_row = ONES;               // (d & 31) != 0: V^T row d of the last tile is all ones: O^T row d = the softmax denominator
+    // (a template parameter since round 3: as a run-time flag it left a conditional add behind every v_exp)
 
     // Q fragments, pre-scaled: lane (query l31, half lh) holds bytes [32*s + 16*lh, +16) of its query row
     u32x4 qf[QSTEPS];
@@ -438,11 +439,15 @@ attn2_kernel(const AttnP p) {
                     for (int r = 0; r < 16; ++r)
                         if (kt0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh >= p.n_valid) st[kb][r] = -INFINITY;
             }
-            float mx = -INFINITY;
+            // one v_max3_f32 per two scores, four independent chains (a single running maximum is a 16-deep dependent chain).  This
+            // file is compiled with -fno-honor-nans (Makefile): with IEEE fmaxf the compiler canonicalises every operand first, 49
+            // v_max_f32 per tile instead of 16 v_max3_f32; a NaN score would poison its row either way.
+            float mxp[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int r = 0; r < 16; r += 2) mx = fmaxf(mx, fmaxf(st[kb][r], st[kb][r + 1]));      // v_max3_f32
+                for (int r = 0; r < 16; r += 2) mxp[(r >> 1) & 3] = fmaxf(mxp[(r >> 1) & 3], fmaxf(st[kb][r], st[kb][r + 1]));
+            float mx = fmaxf(fmaxf(mxp[0], mxp[1]), fmaxf(mxp[2], mxp[3]));
             // (the two lane halves of a query hold different keys; their maxima are only combined when a rescale happens at all --
             // the decision itself is wave-uniform through __any -- so the cross-half exchange leaves the per-tile dependency chain)
             if (first || __any(mx > THR)) {                    // wave-uniform: raise the running maximum, rescale what was accumulated
@@ -517,18 +522,22 @@ attn2_kernel(const AttnP p) {
         }
 }
 
-template <typename T, int DT, int SUB>
-static int attn2_launch(const AttnP& p, hipStream_t st) {
+template <typename T, int DT, int SUB, bool ONES>
+static int attn2_launch_o(const AttnP& p, hipStream_t st) {
     constexpr size_t lds = (size_t)KT * SUB * (DT * 32 * 2 + 16) + (size_t)DT * 32 * (KT * SUB * 2 + 8);
     static bool attr_set = false;
     if (!attr_set) {
-        ADVS_HIP(hipFuncSetAttribute((const void*)attn2_kernel<T, DT, SUB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ADVS_HIP(hipFuncSetAttribute((const void*)attn2_kernel<T, DT, SUB, ONES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     dim3 grid(cdiv(p.N, 128), p.heads, p.B);
-    attn2_kernel<T, DT, SUB><<<grid, AT_THREADS, lds, st>>>(p);
+    attn2_kernel<T, DT, SUB, ONES><<<grid, AT_THREADS, lds, st>>>(p);
     ADVS_CHECK_LAUNCH("attention");
     return ADVS_OK;
+}
+template <typename T, int DT, int SUB>
+static int attn2_launch(const AttnP& p, hipStream_t st) {
+    return (p.d & 31) ? attn2_launch_o<T, DT, SUB, true>(p, st) : attn2_launch_o<T, DT, SUB, false>(p, st);
 }
 
 template <typename T, int DT>

@@ -83,25 +83,26 @@ template <> __device__ __forceinline__ u32x4 pack16<float>(const float* in) {
     for (int i = 0; i < 4; ++i) r[i] = __float_as_uint(in[i]);
     return r;
 }
-template <> __device__ __forceinline__ u32x4 pack16<BF16>(const float* in) {
-    u32x4 r;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-        r[i] = (unsigned)f32_to_bf16(in[2 * i]) | ((unsigned)f32_to_bf16(in[2 * i + 1]) << 16);
-    return r;
-}
 
-template <> __device__ __forceinline__ u32x4 pack16<F16>(const float* in) {
-    u32x4 r;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-        r[i] = (unsigned)f32_to_f16(in[2 * i]) | ((unsigned)f32_to_f16(in[2 * i + 1]) << 16);
-    return r;
-}
 // two f32 -> one packed pair of 16-bit T
 template <typename T> __device__ __forceinline__ unsigned pack2(float lo, float hi);
-template <> __device__ __forceinline__ unsigned pack2<BF16>(float lo, float hi) { return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16); }
-template <> __device__ __forceinline__ unsigned pack2<F16>(float lo, float hi) { return (unsigned)f32_to_f16(lo) | ((unsigned)f32_to_f16(hi) << 16); }
+// (as ONE two-source conversion, v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32: RNE, NaN stays NaN -- the same rounding as two single conversions,
+// a third of the instructions: two conversions plus a shift-or is what the scalar form compiles to)
+typedef float f32x2_cv __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_cv __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_cv __attribute__((ext_vector_type(2)));
+template <> __device__ __forceinline__ unsigned pack2<BF16>(float lo, float hi) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_cv{lo, hi}, bf16x2_cv));
+}
+template <> __device__ __forceinline__ unsigned pack2<F16>(float lo, float hi) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_cv{lo, hi}, f16x2_cv));
+}
+template <> __device__ __forceinline__ u32x4 pack16<BF16>(const float* in) {
+    return u32x4{pack2<BF16>(in[0], in[1]), pack2<BF16>(in[2], in[3]), pack2<BF16>(in[4], in[5]), pack2<BF16>(in[6], in[7])};
+}
+template <> __device__ __forceinline__ u32x4 pack16<F16>(const float* in) {
+    return u32x4{pack2<F16>(in[0], in[1]), pack2<F16>(in[2], in[3]), pack2<F16>(in[4], in[5]), pack2<F16>(in[6], in[7])};
+}
 // K = 16 MFMA on one 16-byte fragment per operand
 template <typename T> __device__ __forceinline__ f32x16 mma16(const u32x4& a, const u32x4& b, const f32x16& c);
 template <> __device__ __forceinline__ f32x16 mma16<BF16>(const u32x4& a, const u32x4& b, const f32x16& c) {
