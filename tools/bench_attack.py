@@ -62,7 +62,7 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     eng = net.grad_engine(a.batch, a.size)
-    tot = bench.conv_profile(eng)
+    tot = {k: v for k, v in bench.conv_profile(eng).items() if "[" not in k}     # (bench.py also returns the conv launches split into groups)
     rec = {"workload": "iterative-gradient attack on " + {"vgg16": "VGG16", "vit": "ViT-B/16", "dinov2": "DINOv2-B/14", "convnext": "ConvNeXt-B", "swin": "Swin-B", "effnet": "EfficientNetV2-S", "resnet50": "ResNet-50"}[a.victim], "size": a.size, "batch": a.batch, "iterations": a.iters,
            "dtype": a.dtype, "images_per_s": a.batch / dt, "s_per_batch": dt,
            "fwd_bwd_ms_by_kernel": {k: round(v[1], 3) for k, v in sorted(tot.items())},

@@ -44,7 +44,7 @@ def main():
         diff.sample(net, a.batch, labels=labels, cfg_scale=3, x_T=xT)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 2
-    tot = bench.conv_profile(_PlanView(net.engine(a.batch), "cfg"))
+    tot = {k: v for k, v in bench.conv_profile(_PlanView(net.engine(a.batch), "cfg")).items() if "[" not in k}     # (bench.py also returns the conv launches split into groups)
     print(json.dumps({"net": a.net, "size": a.size, "batch": a.batch, "ddim_steps": a.steps, "dtype": a.dtype, "cfg": True,
                       "images_per_s": a.batch / dt, "s_per_pass": dt,
                       "cfg_forward_ms_by_kernel": {k: round(v[1], 3) for k, v in sorted(tot.items())},

@@ -32,7 +32,7 @@ def main():
             net(x)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 20
-        tot = bench.conv_profile(net.engine(a.batch, 224))
+        tot = {k: v for k, v in bench.conv_profile(net.engine(a.batch, 224)).items() if "[" not in k}     # (bench.py also returns the conv launches split into groups)
         out[name] = {"images_per_s": a.batch / dt, "ms_per_batch": dt * 1e3,
                      "ms_by_kernel": {k: round(v[1], 3) for k, v in sorted(tot.items())}}
         del net
