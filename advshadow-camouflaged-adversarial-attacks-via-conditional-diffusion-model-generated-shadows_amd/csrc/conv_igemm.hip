@@ -399,9 +399,8 @@ static int resolve_tile(const advs_conv_args* a, long long m_img) {
     // 2-7 %; at 32 x 32 tile 10's 256 workgroups of 8 waves stay ahead.  The rule looks at ONE image's map, never at the batch.
     if (!want && halo2_args_ok(a, 19)) {
         const long long hw = (long long)a->h * a->w_;
-        // (the 4-tap sub-pixel form stages a halo per 64 MFMAs of a wave instead of per 144: the 16 x 32-pixel tile's smaller halo share wins
-        // at every size: 1084 vs 1116 us at 128 -> 256, 252 vs 251 at 64 -> 128)
-        if (a->upsample == ADVS_UPSAMPLE_SUBPIXEL && hw >= 64 * 64 && a->w_ % 32 == 0) return 17;
+        // (sub-pixel upsample convs follow the same rule: in isolation the 16 x 32-pixel tile is 3 % ahead at 128 -> 256 (1084 vs 1116 us),
+        // inside the forward 5 % behind (1049 vs 998 us, profiles/round3_c vs round3_b) -- the forward decides)
         if (hw >= 128 * 128) return 19;
         if (hw >= 64 * 64) return a->w_ % 32 == 0 ? 17 : 19;
     }
