@@ -21,8 +21,11 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--shapes", action="store_true")
+    ap.add_argument("--tile", type=int, default=0, help="advs_conv_set_tile override for every conv that can take it (tuning)")
     a = ap.parse_args()
     lib = _lib.load()
+    if a.tile:
+        lib.advs_conv_set_tile(a.tile)
     torch.manual_seed(0)
     net = UNetModel(compute_dtype=a.dtype, use_graph=False).to("cuda").eval()
     eng = net.engine(a.batch, a.size)
