@@ -117,6 +117,14 @@ template <> __device__ __forceinline__ f32x16 mma16<F16>(const u32x4& a, const u
 __device__ __forceinline__ float silu_fast(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
 }
+// The same SiLU from the PRE-SCALED argument vp = v * log2(e): v * sigmoid(v) = vp / (log2e * (1 + 2^-vp)) = vp * rcp(fma(2^-vp, log2e, log2e)).
+// One VALU slot less per element than silu_fast (the multiply by -log2e is folded into the caller's scale / shift, the add into an FMA): used
+// where GroupNorm's affine feeds the activation (gn_apply_kernel<T, true> and the GroupNorm-on-load transform of conv_halo2.hip, which must
+// agree bit for bit).
+#define ADVS_LOG2E 1.4426950408889634f
+__device__ __forceinline__ float silu_fast_prescaled(float vp) {
+    return vp * __builtin_amdgcn_rcpf(fmaf(__builtin_amdgcn_exp2f(-vp), ADVS_LOG2E, ADVS_LOG2E));
+}
 template <typename T> __device__ __forceinline__ float apply_act_t(float v, int act);
 
 __device__ __forceinline__ float apply_act(float v, int act) {

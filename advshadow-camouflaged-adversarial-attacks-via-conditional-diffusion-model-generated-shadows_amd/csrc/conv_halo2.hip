@@ -216,10 +216,10 @@ conv3x3_halo2_kernel(const ConvKP p) {
             f[0] = f16_to_f32((unsigned short)(raw[0] & 0xffffu)); f[1] = f16_to_f32((unsigned short)(raw[0] >> 16));
             f[2] = f16_to_f32((unsigned short)(raw[1] & 0xffffu)); f[3] = f16_to_f32((unsigned short)(raw[1] >> 16));
         }
-        f[0] = silu_fast(fmaf(f[0], c0[0], c0[1]));
-        f[1] = silu_fast(fmaf(f[1], c0[2], c0[3]));
-        f[2] = silu_fast(fmaf(f[2], c1[0], c1[1]));
-        f[3] = silu_fast(fmaf(f[3], c1[2], c1[3]));
+        f[0] = silu_fast_prescaled(fmaf(f[0], c0[0], c0[1]));      // the table's (scale, shift) carry the factor log2(e)
+        f[1] = silu_fast_prescaled(fmaf(f[1], c0[2], c0[3]));
+        f[2] = silu_fast_prescaled(fmaf(f[2], c1[0], c1[1]));
+        f[3] = silu_fast_prescaled(fmaf(f[3], c1[2], c1[3]));
         const bool live = on && a_pk[j] != 0xFFFFFFFFu;       // (`on` false: the next unit is not a 3x3 unit -- its bytes go back unchanged)
         u32x2 out;
         out[0] = live ? pack2<T>(f[0], f[1]) : raw[0];

@@ -152,6 +152,7 @@ gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ x2, int C1, const
     for (int j = 0; j < VEC; ++j) {
         int c = cv * VEC + j, g = c / cpg;
         gn_channel_affine(s_mean[g], s_rstd[g], gamma[c], beta[c], ca[j], cb[j]);
+        if constexpr (FAST) { ca[j] *= ADVS_LOG2E; cb[j] *= ADVS_LOG2E; }      // silu_fast_prescaled's argument (same two products as gn_affine_kernel)
         cc[j] = cadd ? cadd[(size_t)b * cadd_stride + c] : 0.f;
     }
     const int per = (HW + nblk - 1) / nblk;
@@ -171,7 +172,7 @@ gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ x2, int C1, const
         unpack16<T>(raw, f);
         if constexpr (FAST) {
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) f[j] = silu_fast(fmaf(f[j], ca[j], cb[j]));
+            for (int j = 0; j < VEC; ++j) f[j] = silu_fast_prescaled(fmaf(f[j], ca[j], cb[j]));
             return pack16<T>(f);
         }
         if (rb) unpack16<T>(rraw, r);
@@ -279,7 +280,8 @@ gn_affine_kernel(const float* __restrict__ gamma, const float* __restrict__ beta
     for (int c = tid; c < C; c += GN_THREADS) {
         float sc, sh;
         gn_channel_affine(s_mean[c / cpg], s_rstd[c / cpg], gamma[c], beta[c], sc, sh);
-        *(float2*)(table + ((size_t)b * C + c) * 2) = make_float2(sc, sh);
+        // stored times log2(e): the consumer evaluates SiLU as silu_fast_prescaled(fma(x, scale', shift')), like gn_apply_kernel<T, true>
+        *(float2*)(table + ((size_t)b * C + c) * 2) = make_float2(sc * ADVS_LOG2E, sh * ADVS_LOG2E);
     }
 }
 

@@ -96,8 +96,8 @@ typedef struct advs_conv_args {
                                            residual / act -- ReLU backward fused into a data-gradient conv (the mask is the
                                            forward activation behind the ReLU; train_shadow.py:209 loss.backward()).
                                            Per-tap tiles only (tile 0 | 1 | 4), no stats.                                */
-    const float* norm;                  /* NULL, or [b][c1+c2][2] f32 (scale, shift) from advs_groupnorm_affine_stats: the conv reads
-                                           SiLU(scale * x + shift) in place of x -- GroupNorm + SiLU of the conv's input applied while
+    const float* norm;                  /* NULL, or [b][c1+c2][2] f32 (scale, shift; times log2 e) from advs_groupnorm_affine_stats: the conv reads
+                                           SiLU(GroupNorm(x)) in place of x -- GroupNorm + SiLU of the conv's input applied while
                                            the halo is staged, zero padding staying zero (norm_layer + SiLU + Conv2d, diff_model.py:70-73,
                                            83-86): no normalised tensor in HBM.  Values are rounded to the storage dtype exactly as
                                            advs_groupnorm_stats would have stored them, so the result is bit-identical to the two-pass
@@ -149,7 +149,8 @@ int advs_groupnorm_stats(const void* x, const void* x2, const float* stats1, int
                          int groups, int act, int dtype, void* stream);
 
 /* The (scale, shift) table of GroupNorm(groups) + affine for advs_conv_args.norm, from the same epilogue statistics
- * advs_groupnorm_stats folds: table[b][c][0] = rstd_g * gamma_c, [1] = beta_c - mean_g * rstd_g * gamma_c.
+ * advs_groupnorm_stats folds: table[b][c][0] = log2(e) * rstd_g * gamma_c, [1] = log2(e) * (beta_c - mean_g * rstd_g * gamma_c)
+ * (pre-scaled for the consumer's exp2-based SiLU; the table is an opaque hand-off between these two entry points).
  * scratch as for advs_groupnorm_stats.  table: b * (c + c2) * 2 floats.                                         */
 int advs_groupnorm_affine_stats(const float* stats1, int row_blocks_per_image1, const float* stats2,
                                 int row_blocks_per_image2, const float* gamma, const float* beta, void* scratch,
