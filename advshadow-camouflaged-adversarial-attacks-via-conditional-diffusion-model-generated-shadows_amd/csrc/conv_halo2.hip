@@ -9,16 +9,19 @@
 // LDS-DMA pieces of 60-185 issue cycles each; round 2's ablations put the LDS-DMA issue at 18-24 % and the fragment reads at
 // 10-20 % of the launch (profiles/round2_ablation.txt, round2_halo512.txt).  Geometry H2G512: 16 x 32 pixels with 32-channel units
 // (64 B per pixel) keeps the 18 x 34 halo double-buffered in 80 KiB; eight waves of 64 pixels x 128 channels (2 x 4 MFMA tiles):
-// 12 fragment reads and 1.6 LDS-DMA pieces per 16 MFMAs instead of 16 and 2.7.
+// 12 fragment reads and 1.6 LDS-DMA pieces per 16 MFMAs instead of 16 and 2.7 (-6 % over the layer suite).  Geometry H2G256W4 -- the one
+// advs_conv2d picks from 128 x 128 maps up: 16 x 16 pixels, FOUR waves of 64 pixels x 128 channels, 76 KiB of LDS and <= 256 registers, so
+// that TWO workgroups share a CU and one's prologue / epilogue / barrier stalls run under the other's MFMAs (-8.5 %; -13..-18 % on the level-0
+// shapes whose epilogue is a quarter of the launch).
 //
 // LDS images.  A: halo pixels row-major [y * HW + x][RB bytes], RB = 16 * NCH; the 16-byte chunk c of pixel (y, x) sits in slot
 // c ^ sw(x), sw(x) = (x >> (4 - log2 NCH)) & (NCH - 1).  The 16 lanes of a ds_read_b128 group read 16 CONSECUTIVE columns of one
 // row at one chunk: their slots are distinct mod 256 B for every tap shift (conflict-free), a row shift r is the immediate
-// r * HW * RB, and the column shifts s = 0..2 and k-steps are TM * 3 * KS precomputed registers.  B (weights of one tap): rows
+// r * HW * RB, the column shifts s = 0..2 are TM * 3 precomputed registers and k-step ks is that address ^ (32 * ks).  B (weights of one tap): rows
 // [n][RB] swizzled by n the same way.  The LDS-DMA lands bytes lane-linearly, so the swizzle is applied to the SOURCE chunk: NCH
 // consecutive lanes fetch one pixel's (one weight row's) RB contiguous bytes in permuted order -- whole 64 / 128 B segments per lane
 // group, which is what keeps a piece cheap for the address path.  (First form of this file: a swizzle-free [y][chunk][x] image with
-// all-immediate reads, whose DMA lanes each touch a different pixel: 8 % SLOWER than conv_halo.hip at the same geometry -- the
+// all-immediate reads, whose DMA lanes each touch a different pixel: 7 % SLOWER than conv_halo.hip at the same geometry -- the
 // LDS-DMA's address coalescing, not the address VALU, is what costs; profiles/round3_halo2.txt.)
 // Everything else is conv_halo.hip's scheme: weights three taps ahead in a ring of four stages, ONE barrier per tap, the next
 // unit's halo riding in the first taps of the current one, counted vmcnt literals (taps unrolled), first fragments of the next tap
