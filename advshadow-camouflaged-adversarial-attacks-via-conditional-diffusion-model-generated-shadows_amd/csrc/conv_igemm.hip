@@ -484,7 +484,7 @@ extern "C" int advs_conv2d(const advs_conv_args* a, void* stream) {
     ADVS_REQUIRE(x1b < 0xF0000000ull && x2b < 0xF0000000ull && wb < 0xF0000000ull,
                  "conv2d: a source of %llu bytes exceeds the 32-bit buffer offsets (split the batch)", x1b > x2b ? x1b : x2b);
     p.x1_bytes = (unsigned)x1b; p.x2_bytes = (unsigned)(a->x2 ? x2b : x1b); p.w_bytes = (unsigned)wb;
-    p.act = a->act; p.temb_stride = a->temb_stride > 0 ? a->temb_stride : a->cout;
+    p.act = a->act; p.temb_stride = a->temb_stride > 0 ? a->temb_stride : (a->temb_stride < 0 ? 0 : a->cout);    // < 0: one row for every sample
     p.dHoWo.init((unsigned)(p.Ho * p.Wo)); p.dWo.init((unsigned)p.Wo);
     int tile = resolve_tile(a, (long long)p.Ho * p.Wo);
     ADVS_REQUIRE(tile >= 0, "conv2d: norm (GroupNorm + SiLU on load) needs a 16-bit dtype, 3x3 stride 1 pad 1, no upsample, h and w multiples of 16, c1 + c2 <= 384");

@@ -218,13 +218,16 @@ class UNetModel(nn.Module):
         return W
 
     # ---- plan -------------------------------------------------------------------------------------
-    def engine(self, batch, size, dtype=None):
+    def engine(self, batch, size, dtype=None, uniform_t=False):
+        """uniform_t: the plan of a SAMPLER step -- every image of the batch sits at the same timestep (diff_model.py:447: one ``t`` is
+        broadcast over the batch), so the time-embedding MLP and the stacked per-block Linear run for ONE row that every conv's
+        epilogue reads (timestep_embedding / time_embed hoisting); ``forward(x, t)`` keeps the per-image plan."""
         dt = dtype_code(dtype if dtype is not None else self.compute_dtype)
         W = self.packed_weights(dt)
-        key = (batch, size, dt)
+        key = (batch, size, dt, bool(uniform_t))
         eng = self._engines.get(key)
         if eng is None:
-            eng = _ForwardEngine(self, W, batch, size, dt)
+            eng = _ForwardEngine(self, W, batch, size, dt, uniform_t=bool(uniform_t))
             self._engines[key] = eng
         return eng
 
@@ -248,8 +251,9 @@ class UNetModel(nn.Module):
 class _ForwardEngine:
     """The frozen plan of one UNetModel forward for (batch, size, dtype)."""
 
-    def __init__(self, model, W, batch, size, dt, stream=None):
+    def __init__(self, model, W, batch, size, dt, stream=None, uniform_t=False):
         dev = next(model.parameters()).device
+        self.uniform_t = uniform_t
         self.stream = stream if stream is not None else torch.cuda.Stream(device=dev)
         self.model, self.B, self.S, self.dt = model, batch, size, dt
         with torch.cuda.device(dev):
@@ -258,7 +262,7 @@ class _ForwardEngine:
             self.x = torch.zeros((batch, model.in_channels, size, size), dtype=torch.float32, device=dev)
             self.t = torch.zeros((batch,), dtype=torch.int64, device=dev)
             self.eps = torch.zeros((batch, model.out_channels, size, size), dtype=torch.float32, device=dev)
-            emit_unet_forward(bld, model, W, self.x, self.t, self.eps)
+            emit_unet_forward(bld, model, W, self.x, self.t, self.eps, uniform_t=uniform_t)
             self.plan = bld.plan
             self.captured = False
             torch.cuda.synchronize(dev)
@@ -273,16 +277,16 @@ class _ForwardEngine:
         self.plan.run()
 
 
-def emit_unet_forward(bld, model, W, x_nchw, t_dev, eps_out):
-    """Append the kernels of one forward (diff_model.py:245-267) to ``bld.plan``."""
+def emit_unet_forward(bld, model, W, x_nchw, t_dev, eps_out, uniform_t=False):
+    """Append the kernels of one forward (diff_model.py:245-267) to ``bld.plan``.  uniform_t: t_dev[0] is every image's timestep."""
     heads = model.num_heads
     down, middle, up = model.layout
     # time embedding MLP (diff_model.py:254) and every block's time_emb Linear, hoisted in front
-    e0 = bld.timestep_embedding(t_dev, W["freqs"], cos_first=True)
+    e0 = bld.timestep_embedding(t_dev, W["freqs"], cos_first=True, rows=1 if uniform_t else None)
     e1 = bld.linear(e0, W["time_embed.0.w"], W["time_embed.0.b"], act_out="silu")
     emb = bld.linear(e1, W["time_embed.2.w"], W["time_embed.2.b"])
     temb = bld.linear(emb, W["temb_w"], W["temb_b"], act_in="silu")          # [B, sum cout]
-    tstride = W["temb_total"]
+    tstride = -1 if uniform_t else W["temb_total"]           # -1: one embedding row for the whole batch (advs_conv_args.temb_stride)
 
     fuse = getattr(model, "fuse_norm", True)
 
@@ -500,7 +504,7 @@ class GaussianDiffusion:
         skips the T-1 intermediate device->host copies and returns a one-element list."""
         batch_size, channels, image_size = shape[0], shape[1], shape[2]
         dev = next(model.parameters()).device
-        eng = model.engine(batch_size, image_size)
+        eng = model.engine(batch_size, image_size, uniform_t=True)
         key = (id(eng), bool(clip_denoised))
         loop = self._ancestral.get(key)
         if loop is None:
@@ -565,7 +569,7 @@ class GaussianDiffusion:
         injects the starting noise (otherwise drawn on the model's device as the reference does,
         diff_model.py:444); ``return_tensor`` skips the final ``.cpu().numpy()``."""
         dev = next(model.parameters()).device
-        eng = model.engine(batch_size, image_size)
+        eng = model.engine(batch_size, image_size, uniform_t=True)
         lib = _lib.load()
         coef, tseq = self._tables(ddim_timesteps, ddim_discr_method, ddim_eta, dev)
         nsteps = tseq.numel()

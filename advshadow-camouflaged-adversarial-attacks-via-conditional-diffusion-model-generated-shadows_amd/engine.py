@@ -311,11 +311,13 @@ class Builder:
                       keep=(x, w, bias, y))
         return y
 
-    def timestep_embedding(self, t, freqs, cos_first, table=None, labels=None):
+    def timestep_embedding(self, t, freqs, cos_first, table=None, labels=None, rows=None):
+        """rows: embed only the first ``rows`` timesteps (1 in a sampler step, where every sample sits at the same timestep)."""
         half = freqs.numel()
-        y = self.buf((self.B, 2 * half), torch.float32)
+        n = self.B if rows is None else rows
+        y = self.buf((n, 2 * half), torch.float32)
         self.plan.add(self.lib.advs_timestep_embedding, ptr(t), ptr(freqs), half, 1 if cos_first else 0, ptr(table),
-                      ptr(labels), ptr(y), self.B, keep=(t, freqs, table, labels, y))
+                      ptr(labels), ptr(y), n, keep=(t, freqs, table, labels, y))
         return y
 
 

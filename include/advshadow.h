@@ -71,7 +71,8 @@ typedef struct advs_conv_args {
                                            rows {w0, w1+w2} for a = 0, {w0+w1, w2} for a = 1, columns likewise.
                                            3x3 stride 1 pad 1, h and w multiples of 16.                          */
     int act, dtype;                     /* act may carry ADVS_GN_RESIDUAL_AFTER_ACT: y = act(conv + bias) + residual */
-    int temb_stride;                    /* floats between consecutive samples' temb rows    */
+    int temb_stride;                    /* floats between consecutive samples' temb rows (0: cout); < 0: ONE row shared by
+                                           every sample -- a sampler step, where the whole batch sits at one timestep     */
     int tile;                           /* 0 = choose; 1: 128x128, 2|3: 256x128, 4: 256x256,
                                            10: 16x16-pixel halo tile (3x3 stride 1 only); 12 (implied by
                                            ADVS_UPSAMPLE_SUBPIXEL): its 4-tap sub-pixel form;

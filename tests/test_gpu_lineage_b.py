@@ -382,3 +382,25 @@ def test_every_conv_launch_of_the_headline_forward_is_bit_reproducible():
     spec.loader.exec_module(mod)
     assert mod.main(["--convs-only", "--reps", "3"]) == 0
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_sampler_plan_with_one_timestep_equals_the_per_image_plan(dt):
+    """The sampler replays a plan whose time-embedding MLP runs for ONE row (every image of a step sits at the same timestep,
+    diff_model.py:447); it must produce the bits of the per-image plan ``forward(x, t)`` uses when t is uniform, and a DDIM loop on it
+    the golden result (the golden loops above all run on it)."""
+    torch.manual_seed(3)
+    net = UNetModel(compute_dtype=dt, **CASES["small"][1]).to("cuda").eval()
+    x = torch.randn(3, 3, 32, 32, generator=torch.Generator().manual_seed(12)).cuda()
+    t = torch.full((3,), 441, dtype=torch.long, device="cuda")
+    ref = net(x, t)
+    eng = net.engine(3, 32, uniform_t=True)
+    names = [a for fn, a in eng.plan.ops if fn.__name__ == "advs_timestep_embedding"]
+    assert len(names) == 1 and names[0][-1] == 1                       # one row embedded
+    with torch.cuda.stream(eng.stream):
+        eng.x.copy_(x)
+        eng.t.copy_(t)
+        eng.run()
+        got = eng.eps.clone()
+    eng.stream.synchronize()
+    assert torch.equal(got, ref)

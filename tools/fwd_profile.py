@@ -28,7 +28,7 @@ def main():
         lib.advs_conv_set_tile(a.tile)
     torch.manual_seed(0)
     net = UNetModel(compute_dtype=a.dtype, use_graph=False).to("cuda").eval()
-    eng = net.engine(a.batch, a.size)
+    eng = net.engine(a.batch, a.size, uniform_t=True)       # the sampler's plan (bench.py profiles the same one)
     eng.x.copy_(torch.randn(eng.x.shape, generator=torch.Generator().manual_seed(1)).cuda())
     eng.t.fill_(501)
     s = eng.stream.cuda_stream
