@@ -734,3 +734,67 @@ def test_unknown_dtype_code_is_rejected():
     fn, args = op.b.plan.ops[-1]
     args[0]._obj.dtype = 9
     assert fn(*args, op.stream.cuda_stream) != 0 and "unknown dtype" in lib.advs_last_error().decode()
+
+
+# ------------------------------------------------------------------------------ second-generation halo tiles: seeded random shapes
+def _halo2_random_cases(n=30):
+    rs = np.random.RandomState(20251005)
+    cases = []
+    for _ in range(n):
+        tile = int(rs.choice([17, 18, 19]))
+        B = int(rs.randint(1, 4))
+        H = 16 * int(rs.randint(1, 4))
+        W = (32 if tile == 17 else 16) * int(rs.randint(1, 4))
+        C1 = 64 * int(rs.randint(1, 4))
+        C2 = 64 * int(rs.randint(0, 3))
+        Cout = 8 * int(rs.choice([4, 8, 16, 20, 24, 32, 40]))
+        kind = int(rs.randint(0, 4))                   # 0 plain fast epilogue, 1 residual (generic), 2 fused 1x1 operand, 3 sub-pixel upsample
+        E = (64 * int(rs.randint(1, 3)), 64 * int(rs.randint(0, 2))) if kind == 2 else (0, 0)
+        cases.append((tile, B, H, W, C1, C2, Cout, kind, E, bool(rs.randint(0, 2)), rs.choice(["bf16", "fp16"])))
+    return cases
+
+
+@pytest.mark.parametrize("case", _halo2_random_cases(), ids=lambda c: "t%d-%dx%dx%d-c%d+%d-o%d-k%d" % c[:8])
+def test_conv2d_halo2_random_shapes(case):
+    """Tiles 17-19 on seeded random shapes (batch 1-3, 1-3 tiles each way, one to five units per source, output-channel tails,
+    all three kernel kinds, both epilogues) against the per-tap implicit-GEMM tile 1 -- another kernel, the same arithmetic in
+    another order -- and the epilogue statistics against the sums of what was stored."""
+    tile, B, H, W, C1, C2, Cout, kind, (E1, E2), has_t, dt = case
+    code = dtype_code(dt)
+    x1 = rnd(B, C1, H, W, seed=201)
+    x2 = rnd(B, C2, H, W, seed=202) if C2 else None
+    w = rnd(Cout, C1 + C2, 3, 3, seed=203, scale=1.0 / math.sqrt(9 * (C1 + C2)))
+    bias = rnd(Cout, seed=204)
+    ups = kind == 3
+    Ho, Wo = (2 * H, 2 * W) if ups else (H, W)
+    temb = rnd(B, Cout, seed=205) if has_t and kind != 1 else None
+    res = rnd(B, Cout, Ho, Wo, seed=206) if kind == 1 else None
+    e1 = rnd(B, E1, H, W, seed=207) if E1 else None
+    e2 = rnd(B, E2, H, W, seed=208) if E2 else None
+
+    def run(t):
+        op = OneOp(dt, B)
+        wp = pack_subpixel_upsample_weight(w.to(dev()), code) if ups else pack_conv_weight(w.to(dev()), code)
+        kw = {}
+        if E1:
+            w1 = rnd(Cout, E1 + E2, 1, 1, seed=209, scale=1 / math.sqrt(E1 + E2))
+            wp = torch.cat([wp.reshape(Cout, -1), pack_conv_weight(w1.to(dev()), code).reshape(Cout, -1)], 1).contiguous()
+            kw["extra"] = (nhwc(e1, dt), nhwc(e2, dt) if E2 else None)
+        y = op.b.conv(nhwc(x1, dt), wp, Cout, x2=nhwc(x2, dt) if C2 else None, bias=bias.to(dev()),
+                      temb=temb.to(dev()) if temb is not None else None, temb_stride=Cout if temb is not None else 0,
+                      residual=nhwc(res, dt) if res is not None else None, upsample="subpixel" if ups else False, tile=t,
+                      want_stats=True, **kw)
+        st = op.b.stats.get(y.data_ptr())
+        op.go()
+        return y.float().cpu(), (st[0].cpu() if st is not None else None)
+
+    got, st = run(tile)
+    ref, _ = run(0 if ups else 1)        # sub-pixel weights exist on the halo kernels only: the default rule (another tile) is the reference
+    if ups and Ho * Wo >= 64 * 64 * 4:
+        pytest.skip("the default rule picks the same family here")
+    err = (got - ref).abs().max().item()
+    assert err < 4e-2, err
+    assert st is not None and st.shape[1] == Cout
+    tot = st.view(B, -1, Cout, 2).sum(1).double()
+    yy = got.double().view(B, -1, Cout)
+    assert torch.allclose(tot[..., 0], yy.sum(1), rtol=1e-3, atol=5e-2) and torch.allclose(tot[..., 1], (yy * yy).sum(1), rtol=1e-3, atol=5e-2)
