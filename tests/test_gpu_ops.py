@@ -507,6 +507,9 @@ def test_conv2d_extra_operand_on_the_halo_kernel(case, dt, tile):
     (2, 16, 32, (128, 0), 128, 0, 1, (0, 0)),          # conv2 with the identity shortcut: generic epilogue
     (1, 32, 32, (128, 0), 128, 0, 0, (128, 256)),      # conv2 with the fused 1x1 shortcut: extra units stay un-normalised
     (3, 16, 16, (64, 0), 64, 1, 0, (0, 0)),            # two units, N tail, image edges everywhere
+    (1, 16, 48, (192, 192), 96, 1, 0, (0, 0)),         # the widest table the kernel takes (384 channels), 12 channels a group, N tail
+    (3, 32, 16, (256, 0), 40, 0, 1, (0, 0)),           # residual epilogue with a 40-channel tail
+    (2, 16, 16, (64, 64), 128, 1, 0, (64, 0)),         # two normalised sources and ONE un-normalised extra source
 ])
 def test_conv2d_norm_on_load(case, dt):
     """conv3x3(SiLU(GroupNorm32(x))) with the norm applied while the halo is staged must equal, BIT FOR BIT, the two-pass form
