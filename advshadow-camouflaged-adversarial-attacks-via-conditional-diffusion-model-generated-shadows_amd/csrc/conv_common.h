@@ -72,9 +72,11 @@ template <> struct Mma<float> {
 //   row_to_m(lr): output pixel index of the wave's local row lr (0 .. TM*32), or -1 when out of range
 //   temb_b: batch index when every row of the wave shares it (temb folded into the bias), -1 = per row
 //   rb: row-block index for the epilogue statistics, -1 = this wave writes none
+//   wave_stats: null, or WN (sum, sum of squares) pairs in LDS that take the wave's statistics INSTEAD of p.stats -- the caller then
+//               adds the waves of its workgroup up (conv_halo2.hip: one entry per workgroup, a quarter / an eighth of the bytes)
 template <typename T, int WN, int TM, int TN, bool MASK = false, typename RowMap>
 __device__ __forceinline__ void conv_epilogue(const ConvKP& p, f32x16 (&acc)[TM][TN], float* patch, int lane,
-                                              int ncol0, RowMap row_to_m, int temb_b, int rb) {
+                                              int ncol0, RowMap row_to_m, int temb_b, int rb, float2* wave_stats = nullptr) {
     constexpr int VEC = 16 / Mma<T>::ESZ;
     constexpr int LPR = WN / VEC;                 // lanes per patch row
     constexpr int RPI = 64 / LPR;                 // rows per wave-instruction
@@ -181,7 +183,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvKP& p, f32x16 (&acc)[TM]
         for (int o = LPR; o < 64; o <<= 1)
 #pragma unroll
             for (int e = 0; e < VEC; ++e) { ssum[e] += __shfl_xor(ssum[e], o); ssq[e] += __shfl_xor(ssq[e], o); }
-        if (prow == 0 && n_ok && rb >= 0) {
+        if (wave_stats) {                            // channels past Cout carry zeros
+            if (prow == 0) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) wave_stats[pcv * VEC + e] = make_float2(ssum[e], ssq[e]);
+            }
+        } else if (prow == 0 && n_ok && rb >= 0) {
             float* sp = p.stats + ((size_t)rb * p.Cout + n) * 2;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) { sp[2 * e] = ssum[e]; sp[2 * e + 1] = ssq[e]; }
@@ -234,7 +241,7 @@ __device__ __forceinline__ void conv_acc_init(const ConvKP& p, f32x16 (&acc)[TM]
 
 template <typename T, int WN, int TM, int TN, typename RowMap>
 __device__ __forceinline__ void conv_epilogue_fast(const ConvKP& p, f32x16 (&acc)[TM][TN], char* patch, int lane, int ncol0,
-                                                   RowMap row_to_m, int rb) {
+                                                   RowMap row_to_m, int rb, float2* wave_stats = nullptr) {
     static_assert(WN == TN * 32, "one wave owns TN channel tiles");
     constexpr int ROWB = WN * 2;                  // bytes of one patch row (16-bit elements)
     constexpr int LPR = ROWB / 16, RPI = 64 / LPR;
@@ -283,7 +290,9 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvKP& p, f32x16 (&acc
         for (int j = 0; j < TN; ++j) {                               // the two lane halves hold the other 16 rows of the same channel
             const float s = ssum[j] + __shfl_xor(ssum[j], 32), q = ssq[j] + __shfl_xor(ssq[j], 32);
             const int c = ncol0 + j * 32 + l31;
-            if (lh == 0 && c < p.Cout) {
+            if (wave_stats) {
+                if (lh == 0) wave_stats[j * 32 + l31] = make_float2(s, q);
+            } else if (lh == 0 && c < p.Cout) {
                 float2* sp = (float2*)(p.stats + ((size_t)rb * p.Cout + c) * 2);
                 *sp = make_float2(s, q);
             }

@@ -60,7 +60,7 @@ struct H2Geom {
     static_assert(TM * WM * 32 == TY * TX && TM >= 1, "pixel tiles divide over the waves");
     static_assert(NAP <= 6, "the halo pieces of a unit ride one per tap in taps 0..5");
     static_assert(NCH == 4 || NCH == 8, "64- or 128-byte pixel rows");
-    static_assert(TM == 2, "a wave owns 64 pixel rows (the statistics' row block)");
+    static_assert(TM == 2 && TY * TX == WM * 64, "a wave owns 64 pixel rows, a workgroup one statistics row block of WM * 64");
 };
 
 // MFMA row r of a 32-row tile <-> (strip g, column idx) of two 16-pixel strips (conv_halo.hip: halo_row_map): each ds_read_b128
@@ -422,13 +422,33 @@ conv3x3_halo2_kernel(const ConvKP p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                    // every wave is done reading before the patches reuse LDS
 
-    const int rb = (tl * NPAR + par) * G::WM + wm;
+    // Epilogue statistics: ONE (sum, sum of squares) entry per workgroup and channel.  Each wave leaves its 64 rows' sums at the head of
+    // its own (by then idle) patch, and after a barrier 128 threads add the WM waves of their channel up in wave order.  [One entry per
+    // wave until round 3: at the level-0 shapes that was 33.5 MB of statistics per launch against 537 MB of y -- written here, read again
+    // by the fold -- now a quarter (tiles 18/19) or an eighth (tile 17).]
+    const int rb = tl * NPAR + par;
     if (p.fast_epi) {
-        conv_epilogue_fast<T, G::WNC, TM, TN>(p, acc, smem + wave * (32 * G::WNC * 2), lane, n0 + wn * G::WNC, row_to_m, rb);
-        return;
+        char* patch = smem + wave * (32 * G::WNC * 2);
+        conv_epilogue_fast<T, G::WNC, TM, TN>(p, acc, patch, lane, n0 + wn * G::WNC, row_to_m, rb, p.stats ? (float2*)patch : nullptr);
+    } else {
+        float* patch = (float*)smem + wave * (32 * G::WNC);
+        conv_epilogue<T, G::WNC, TM, TN>(p, acc, patch, lane, n0 + wn * G::WNC, row_to_m, p.temb ? b : -1, rb, p.stats ? (float2*)patch : nullptr);
     }
-    conv_epilogue<T, G::WNC, TM, TN>(p, acc, (float*)smem + wave * (32 * G::WNC), lane, n0 + wn * G::WNC, row_to_m,
-                                     p.temb ? b : -1, rb);
+    if (!p.stats) return;
+    __syncthreads();
+    if (tid < 128) {
+        const int cw = tid / G::WNC, cc = tid - cw * G::WNC;          // the wave column that owns channel tid, and its slot there
+        const int pstride = p.fast_epi ? 32 * G::WNC * 2 : 32 * G::WNC * 4;
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int w = 0; w < G::WM; ++w) {
+            const float2 v = ((const float2*)(smem + (w * G::WN + cw) * pstride))[cc];
+            s += v.x;
+            q += v.y;
+        }
+        const int c = n0 + tid;
+        if (c < p.Cout) *(float2*)(p.stats + ((size_t)rb * p.Cout + c) * 2) = make_float2(s, q);
+    }
 }
 
 // ---- host side

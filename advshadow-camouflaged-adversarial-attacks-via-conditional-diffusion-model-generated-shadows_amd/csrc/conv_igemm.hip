@@ -424,7 +424,9 @@ extern "C" int advs_conv_resolve_tile(const advs_conv_args* a) {
 }
 extern "C" int advs_conv_tile_rows(int tile) {
     switch (tile) {
-        case 1: case 2: case 5: case 6: case 8: case 10: case 12: case 13: case 17: case 18: case 19: return 64;
+        case 1: case 2: case 5: case 6: case 8: case 10: case 12: case 13: return 64;
+        case 18: case 19: return 256;       // conv_halo2.hip: one entry per workgroup
+        case 17: return 512;
         case 3: case 4: case 7: case 9: return 128;
         case 15: case 16: return 32;
         default: return 0;

@@ -224,7 +224,9 @@ class Builder:
     def can_fuse_norm(self, x, x2, cout, ksize=3):
         """GroupNorm + SiLU applied inside the conv that reads it (advs_conv_args.norm)?  16-bit storage, a 3x3 conv on a map the
         4-wave halo tile takes (>= 128 x 128, multiples of 16), one 128-channel output tile -- with two the transform would run
-        twice per element -- at most NORM_MAXC input channels, statistics of every source available from its producer."""
+        twice per element: measured at level 1 (128 x 128, 256 outputs; round 3, one box) the convs grow by 1.10 ms for 1.07 ms of
+        norm passes saved, and with only the two 512-channel ones by 0.42 for 0.36 -- at most NORM_MAXC input channels, statistics
+        of every source available from its producer."""
         B, H, W, C1 = x.shape
         C2 = 0 if x2 is None else x2.shape[3]
         if self.dt == F32 or ksize != 3 or cout > 128 or C1 + C2 > self.NORM_MAXC or C1 % 64 or C2 % 64:

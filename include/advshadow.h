@@ -107,7 +107,8 @@ typedef struct advs_conv_args {
 int advs_conv2d(const advs_conv_args* a, void* stream);
 int advs_conv_set_tile(int tile);       /* tuning hook: non-zero overrides every call's tile  */
 int advs_conv_resolve_tile(const advs_conv_args* a);   /* the tile id advs_conv2d will use for this descriptor */
-int advs_conv_tile_rows(int tile);      /* row-block height (rows per stats entry) of a tile id */
+int advs_conv_tile_rows(int tile);      /* row-block height (rows per stats entry) of a tile id: 64 per wave for the older
+                                           tiles, one entry per WORKGROUP for 17 (512), 18 and 19 (256) */
 
 /* First conv: NCHW f32 image (cin <= 4) -> NHWC `dtype`, 3x3 pad 1 (diff_model.py:192;
  * model/modules/conv.py:38 for inc).  w is the torch OIHW f32 weight.                      */
