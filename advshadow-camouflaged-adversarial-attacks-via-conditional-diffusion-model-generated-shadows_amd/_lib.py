@@ -26,6 +26,13 @@ class ConvArgs(C.Structure):
                 ("ld1", i32), ("ld2", i32), ("relu_mask", vp), ("norm", vp)]
 
 
+class UNetConfig(C.Structure):
+    """include/advshadow.h: advs_unet_config (diff_model.UNetModel's constructor arguments)."""
+    _fields_ = [("in_channels", i32), ("model_channels", i32), ("out_channels", i32), ("num_res_blocks", i32),
+                ("n_attention_resolutions", i32), ("attention_resolutions", i32 * 8),
+                ("n_channel_mult", i32), ("channel_mult", i32 * 8), ("num_heads", i32), ("dtype", i32)]
+
+
 # name -> argtypes (restype is int unless listed in _RESTYPES)
 SIGNATURES = {
     "advs_init": [],
@@ -124,11 +131,20 @@ SIGNATURES = {
     "advs_event_elapsed_ms": [vp, vp, C.POINTER(f32)],
     "advs_event_destroy": [vp],
     "advs_stream_sync": [vp],
+    # handle-level entry points (csrc/unet_handle.hip; handle.py is their ctypes view)
+    "advs_unet_create": [C.POINTER(UNetConfig), C.POINTER(vp)],
+    "advs_unet_param_count": [vp],
+    "advs_unet_param_name": [vp, i32, C.c_char_p, i32, C.POINTER(C.c_longlong)],
+    "advs_unet_set_param": [vp, C.c_char_p, vp, C.c_longlong],
+    "advs_unet_plan": [vp, i32, i32, i32, vp],
+    "advs_unet_forward": [vp, vp, vp, vp],
+    "advs_ddim_tables": [i32, i32, i32, i32, f32, vp, vp, C.POINTER(i32)],
+    "advs_ddim_run": [vp, vp, vp, vp, i32, i32],
 }
 _RESTYPES = {"advs_last_error": C.c_char_p, "advs_groupnorm_scratch_bytes": sz, "advs_jpeg_scratch_bytes": sz,
-             "advs_mask_contours_work_bytes": sz, "advs_attention_bwd_scratch_bytes": sz}
+             "advs_mask_contours_work_bytes": sz, "advs_attention_bwd_scratch_bytes": sz, "advs_unet_destroy": None}
 _EXTRA = {"advs_last_error": [], "advs_groupnorm_scratch_bytes": [i32, i32], "advs_jpeg_scratch_bytes": [i32, i32, i32],
-          "advs_mask_contours_work_bytes": [i32, i32, i32], "advs_attention_bwd_scratch_bytes": [i32, i32, i32]}
+          "advs_mask_contours_work_bytes": [i32, i32, i32], "advs_attention_bwd_scratch_bytes": [i32, i32, i32], "advs_unet_destroy": [vp]}
 
 _lib = None
 

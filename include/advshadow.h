@@ -452,6 +452,38 @@ int advs_vit_assemble(const void* patches, const float* cls, const float* pos, v
                       int n_pad, int c, int dtype, void* stream);
 int advs_gather_rows_f32(const void* x, float* y, int b, long long row_stride, int c, int dtype, void* stream);
 
+/* ---- handle-level entry points: a host without Python drives the eps-predictor and the DDIM loop -------------------------------
+ * The op-level calls above are what the Python plan builder binds (engine.py / diff_model.py of the package); these restate that
+ * plan in C++ (csrc/unet_handle.hip) for a caller that has only the C ABI: same kernels, same order, same bits.
+ *   advs_unet_create      diff_model.UNetModel's constructor arguments (diff_model.py:163-175).
+ *   advs_unet_param_*     the state_dict keys and element counts the network expects, in the reference's construction order.
+ *   advs_unet_set_param   one state_dict tensor (host f32, torch layout).  The optional name "freqs" overrides the sinusoidal
+ *                         embedding's frequency table (model_channels / 2 floats, diff_model.py:26-28) with the caller's bits.
+ *   advs_unet_plan        packs the weights (once), builds the launch list of one forward for (batch, size) on `stream` and captures
+ *                         it into a hipGraph.  uniform_t = 1: the sampler's plan, one timestep (t[0]) for the whole batch.
+ *   advs_unet_forward     eps = model(x, t) (diff_model.py:245-267); x, eps NCHW f32 and t int64, all DEVICE pointers; stream-ordered.
+ *   advs_ddim_tables      per-step (alpha_t, alpha_prev, sigma) and timesteps in loop order (diff_model.py:269-285, 304, 428-464);
+ *                         coef_out / tseq_out NULL = size query (*nsteps_out only).  Host arrays.
+ *   advs_ddim_run         the reverse loop (diff_model.py:442-474) with eta = 0: x holds x_T on entry, the sample on return.       */
+typedef struct advs_unet advs_unet;
+typedef struct advs_unet_config {
+    int in_channels, model_channels, out_channels, num_res_blocks;
+    int n_attention_resolutions, attention_resolutions[8];
+    int n_channel_mult, channel_mult[8];
+    int num_heads;
+    int dtype;                          /* ADVS_F32 | ADVS_BF16 | ADVS_F16 */
+} advs_unet_config;
+int advs_unet_create(const advs_unet_config* cfg, advs_unet** out);
+int advs_unet_param_count(const advs_unet* u);
+int advs_unet_param_name(const advs_unet* u, int i, char* name, int name_len, long long* numel);
+int advs_unet_set_param(advs_unet* u, const char* name, const float* host_data, long long numel);
+int advs_unet_plan(advs_unet* u, int batch, int size, int uniform_t, void* stream);
+int advs_unet_forward(advs_unet* u, const float* x_nchw, const int64_t* t, float* eps_nchw);
+int advs_ddim_tables(int cosine_schedule, int timesteps, int ddim_timesteps, int quad, float eta, float* coef_out,
+                     int64_t* tseq_out, int* nsteps_out);
+int advs_ddim_run(advs_unet* u, float* x, const float* coef, const int64_t* tseq, int nsteps, int clip_denoised);
+void advs_unet_destroy(advs_unet* u);
+
 /* ---- stream capture (hipGraph) -------------------------------------------------------- */
 int advs_graph_begin(void* stream);
 int advs_graph_end(void* stream, void** graph_exec_out);
