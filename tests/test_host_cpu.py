@@ -142,3 +142,54 @@ def test_gradient_attack_host_logic():
         adversarial._mask4(torch.ones(2, 8, 8), 1, 3, 8, 8, cpu)
     with pytest.raises(ValueError):
         adversarial._mask4(torch.ones(1, 8, 9), 1, 3, 8, 8, cpu)
+
+
+# ------------------------------------------------------------------------------ handle-level entry points: the host-only part
+@pytest.mark.parametrize("tag", list(CASES))
+def test_handle_param_registry_is_the_reference_state_dict(tag):
+    """advs_unet_create / _param_count / _param_name (csrc/unet_handle.hip) need no GPU: the names and sizes a C host must supply are
+    the state_dict of diff_model.UNetModel, in the reference's construction order (diff_model.py:163-243)."""
+    import ctypes as C
+    from advshadow_amd._lib import UNetConfig
+    from advshadow_amd.diff_model import UNetModel
+    _, kw = CASES[tag]
+    net = UNetModel(**kw)
+    cfg = UNetConfig()
+    cfg.in_channels, cfg.model_channels, cfg.out_channels, cfg.num_res_blocks = 3, net.model_channels, 3, net.num_res_blocks
+    cfg.n_attention_resolutions, cfg.n_channel_mult = len(net.attention_resolutions), len(net.channel_mult)
+    for i, v in enumerate(net.attention_resolutions):
+        cfg.attention_resolutions[i] = v
+    for i, v in enumerate(net.channel_mult):
+        cfg.channel_mult[i] = v
+    cfg.num_heads, cfg.dtype = net.num_heads, 1
+    lib = _lib.load()
+    h = C.c_void_p()
+    assert lib.advs_unet_create(C.byref(cfg), C.byref(h)) == 0
+    buf, n = C.create_string_buffer(256), C.c_longlong()
+    got = []
+    for i in range(lib.advs_unet_param_count(h)):
+        assert lib.advs_unet_param_name(h, i, buf, 256, C.byref(n)) == 0
+        got.append((buf.value.decode(), n.value))
+    assert got == [(k, v.numel()) for k, v in net.state_dict().items()]
+    assert lib.advs_unet_set_param(h, b"no.such.weight", None, 0) != 0
+    lib.advs_unet_destroy(h)
+    cfg.dtype = 9
+    assert lib.advs_unet_create(C.byref(cfg), C.byref(h)) != 0 and b"dtype" in lib.advs_last_error()
+
+
+@pytest.mark.parametrize("sched,method,n", [("cosine", "uniform", 50), ("linear", "uniform", 50), ("cosine", "quad", 20), ("linear", "quad", 50), ("cosine", "uniform", 30)])
+def test_handle_ddim_tables_vs_float64_tables(sched, method, n):
+    """advs_ddim_tables (host code) against GaussianDiffusion._tables: same timesteps, coefficients within one f32 ulp (libm's cos against torch's)."""
+    import ctypes as C
+    from advshadow_amd.diff_model import GaussianDiffusion
+    diff = GaussianDiffusion(timesteps=1000, beta_schedule=sched)
+    coef, tseq = diff._tables(n, method, 0.0, torch.device("cpu"))
+    lib = _lib.load()
+    cnt = C.c_int()
+    args = (1 if sched == "cosine" else 0, 1000, n, 1 if method == "quad" else 0, 0.0)
+    assert lib.advs_ddim_tables(*args, None, None, C.byref(cnt)) == 0 and cnt.value == len(tseq)
+    c2, t2 = np.zeros((cnt.value, 3), np.float32), np.zeros(cnt.value, np.int64)
+    assert lib.advs_ddim_tables(*args, c2.ctypes.data, t2.ctypes.data, C.byref(cnt)) == 0
+    assert np.array_equal(t2, tseq.numpy())
+    assert np.allclose(c2, coef.numpy(), rtol=2e-7, atol=0)
+    assert lib.advs_ddim_tables(1, 1000, 0, 0, 0.0, None, None, C.byref(cnt)) != 0
