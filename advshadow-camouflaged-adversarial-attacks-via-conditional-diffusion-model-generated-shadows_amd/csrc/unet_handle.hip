@@ -632,6 +632,7 @@ extern "C" int advs_unet_param_count(const advs_unet* u) { return u ? (int)u->pa
 
 extern "C" int advs_unet_param_name(const advs_unet* u, int i, char* name, int name_len, long long* numel) {
     ADVS_REQUIRE(u && i >= 0 && i < (int)u->params.size() && name && name_len > 0, "advs_unet_param_name: bad index");
+    ADVS_REQUIRE((int)u->params[i].first.size() < name_len, "advs_unet_param_name: %d bytes are too few for %s", name_len, u->params[i].first.c_str());
     snprintf(name, (size_t)name_len, "%s", u->params[i].first.c_str());
     if (numel) *numel = u->params[i].second;
     return ADVS_OK;
