@@ -11,6 +11,9 @@
  *   - activations are NHWC ("channels last": [B][H][W][C]); dtype ADVS_F32, ADVS_BF16 or ADVS_F16;
  *   - every call enqueues on the given hipStream_t (passed as void*), never synchronises,
  *     allocates nothing, and is therefore legal inside stream capture;
+ *   - the ONE exception to the three lines above is the handle-level group at the end (advs_unet_*, advs_ddim_run): for a
+ *     host without a plan builder of its own the library keeps the network, its activations (hipMalloc) and the captured
+ *     launch list behind an opaque handle, and synchronises where it says so;
  *   - return 0 on success, a negative ADVS_ERR_* otherwise; advs_last_error() has the text.
  */
 #ifndef ADVSHADOW_H
