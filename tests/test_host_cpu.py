@@ -193,3 +193,14 @@ def test_handle_ddim_tables_vs_float64_tables(sched, method, n):
     assert np.array_equal(t2, tseq.numpy())
     assert np.allclose(c2, coef.numpy(), rtol=2e-7, atol=0)
     assert lib.advs_ddim_tables(1, 1000, 0, 0, 0.0, None, None, C.byref(cnt)) != 0
+
+
+def test_header_is_valid_c():
+    """include/advshadow.h is what a C host includes (examples/c_host_ddim.c): it has to compile as C11, not only as C++."""
+    import subprocess
+    r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(ROOT, "include", "advshadow.h")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run(["gcc", "-std=c11", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include",
+                        "-fsyntax-only", os.path.join(ROOT, "examples", "c_host_ddim.c")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
