@@ -140,11 +140,19 @@ SIGNATURES = {
     "advs_unet_forward": [vp, vp, vp, vp],
     "advs_ddim_tables": [i32, i32, i32, i32, f32, vp, vp, C.POINTER(i32)],
     "advs_ddim_run": [vp, vp, vp, vp, i32, i32],
+    "advs_resize_tables": [i32, i32, vp, vp, C.POINTER(i32)],
+    "advs_resnet50_create": [i32, i32, C.POINTER(vp)],
+    "advs_resnet50_param_count": [vp],
+    "advs_resnet50_param_name": [vp, i32, C.c_char_p, i32, C.POINTER(C.c_longlong)],
+    "advs_resnet50_set_param": [vp, C.c_char_p, vp, C.c_longlong],
+    "advs_resnet50_plan": [vp, i32, i32, i32, vp],
+    "advs_resnet50_forward": [vp, vp, vp],
+    "advs_resnet50_eval_u8": [vp, vp, vp],
 }
 _RESTYPES = {"advs_last_error": C.c_char_p, "advs_groupnorm_scratch_bytes": sz, "advs_jpeg_scratch_bytes": sz,
-             "advs_mask_contours_work_bytes": sz, "advs_attention_bwd_scratch_bytes": sz, "advs_unet_destroy": None}
+             "advs_mask_contours_work_bytes": sz, "advs_attention_bwd_scratch_bytes": sz, "advs_unet_destroy": None, "advs_resnet50_destroy": None}
 _EXTRA = {"advs_last_error": [], "advs_groupnorm_scratch_bytes": [i32, i32], "advs_jpeg_scratch_bytes": [i32, i32, i32],
-          "advs_mask_contours_work_bytes": [i32, i32, i32], "advs_attention_bwd_scratch_bytes": [i32, i32, i32], "advs_unet_destroy": [vp]}
+          "advs_mask_contours_work_bytes": [i32, i32, i32], "advs_attention_bwd_scratch_bytes": [i32, i32, i32], "advs_unet_destroy": [vp], "advs_resnet50_destroy": [vp]}
 
 _lib = None
 

@@ -804,3 +804,337 @@ extern "C" void advs_unet_destroy(advs_unet* u) {
     for (void* p : u->wbufs) (void)hipFree(p);
     delete u;
 }
+
+// =====================================================================================================================================
+// The victim side of the attack loop for the same kind of host: ResNet-50 (timm / torchvision layout: ASR_fast.py:16-20,
+// ddim2/diff_model2.py:19-44) with BatchNorm folded into the convs, and the evaluation chain of ASR_fast.py:90-126 in front of it
+// (uint8 sampler output -> Pillow-exact Resize((224, 224)) -> ToTensor -> victim -> argmax).  Restates victims.ResNet50 / _ResNetEngine,
+// imageops.bilinear_coeffs / resize_u8 / preprocess_batch and asr.evaluate_batch of this package.
+// =====================================================================================================================================
+struct advs_resnet50 {
+    int num_classes = 0, dtype = 0;
+    struct Blk { std::string p; int cin, width, cout, stride; bool ds; };
+    std::vector<Blk> blocks;
+    std::vector<std::pair<std::string, long long>> params;
+    std::map<std::string, std::vector<float>> host;
+    std::map<std::string, void*> W;
+    std::vector<void*> wbufs;
+    int stem_kp = 0;
+    bool packed = false;
+    // plan
+    int B = 0, S = 0, src = 0;
+    hipStream_t stream = nullptr;
+    Arena arena;
+    std::list<advs_conv_args> cargs;
+    Plan fwd;
+    float *x = nullptr, *logits = nullptr;
+    // evaluation chain buffers
+    unsigned char *hwc = nullptr, *rs1 = nullptr, *rs2 = nullptr;
+    int *bounds = nullptr, *coefs = nullptr, ksize = 0;
+};
+
+// Pillow's precompute_coeffs + normalize_coeffs_8bpc for the BILINEAR filter (libImaging/Resample.c; transforms.Resize on a PIL image,
+// ASR_fast.py:94, PSNR_SSIM_fast.py:10-13): bounds [out][2] = (first source pixel, count), coefs [out][ksize] in 22-bit fixed point.
+extern "C" int advs_resize_tables(int in_size, int out_size, int* bounds, int* coefs, int* ksize_out) {
+    ADVS_REQUIRE(in_size > 0 && out_size > 0 && ksize_out, "advs_resize_tables: bad sizes");
+    const double scale = (double)in_size / out_size, filterscale = scale < 1.0 ? 1.0 : scale, support = 1.0 * filterscale;
+    const int ksize = (int)ceil(support) * 2 + 1;
+    *ksize_out = ksize;
+    if (!bounds || !coefs) return ADVS_OK;                        // size query
+    const double ss = 1.0 / filterscale;
+    std::vector<double> w(ksize);
+    for (int xx = 0; xx < out_size; ++xx) {
+        const double center = (xx + 0.5) * scale;
+        int xmin = (int)(center - support + 0.5);
+        if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5);
+        if (xmax > in_size) xmax = in_size;
+        xmax -= xmin;
+        double ww = 0.0;
+        for (int x = 0; x < xmax; ++x) {
+            const double a = fabs((x + xmin - center + 0.5) * ss);
+            w[x] = a < 1.0 ? 1.0 - a : 0.0;
+            ww += w[x];
+        }
+        for (int x = 0; x < ksize; ++x) {
+            double k = x < xmax ? (ww != 0.0 ? w[x] / ww : w[x]) : 0.0;
+            coefs[xx * ksize + x] = (int)trunc(k < 0 ? -0.5 + k * (1 << 22) : 0.5 + k * (1 << 22));
+        }
+        bounds[2 * xx] = xmin;
+        bounds[2 * xx + 1] = xmax;
+    }
+    return ADVS_OK;
+}
+
+namespace {
+
+void rn_params(advs_resnet50* r) {
+    auto add = [&](const std::string& n, long long k) { r->params.push_back({n, k}); };
+    auto bn = [&](const std::string& p, long long c) { add(p + ".weight", c); add(p + ".bias", c); add(p + ".running_mean", c); add(p + ".running_var", c); };
+    add("conv1.weight", 64 * 3 * 49);
+    bn("bn1", 64);
+    const int layers[4][3] = {{64, 3, 1}, {128, 4, 2}, {256, 6, 2}, {512, 3, 2}};
+    int cin = 64;
+    for (int li = 0; li < 4; ++li)
+        for (int bi = 0; bi < layers[li][1]; ++bi) {
+            const int width = layers[li][0], s = bi == 0 ? layers[li][2] : 1, cout = width * 4;
+            const bool ds = s != 1 || cin != cout;
+            const std::string p = "layer" + std::to_string(li + 1) + "." + std::to_string(bi);
+            add(p + ".conv1.weight", (long long)width * cin); bn(p + ".bn1", width);
+            add(p + ".conv2.weight", (long long)width * width * 9); bn(p + ".bn2", width);
+            add(p + ".conv3.weight", (long long)cout * width); bn(p + ".bn3", cout);
+            if (ds) { add(p + ".downsample.0.weight", (long long)cout * cin); bn(p + ".downsample.1", cout); }
+            r->blocks.push_back({p, cin, width, cout, s, ds});
+            cin = cout;
+        }
+    add("fc.weight", 2048ll * r->num_classes);
+    add("fc.bias", r->num_classes);
+}
+
+int rn_dev_copy(advs_resnet50* r, const float* src, size_t n, void** out) {
+    void* p = nullptr;
+    ADVS_HIP(hipMalloc(&p, n * sizeof(float)));
+    r->wbufs.push_back(p);
+    ADVS_HIP(hipMemcpy(p, src, n * sizeof(float), hipMemcpyHostToDevice));
+    *out = p;
+    return ADVS_OK;
+}
+
+// victims.ResNet50._fold: w * (gamma / sqrt(var + 1e-5)) per output channel, bias = beta - mean * scale (f32), then pack_conv_weight
+// with the input channels padded to whole 128-byte slabs (the 147-column stem)
+int rn_fold_pack(advs_resnet50* r, const std::string& conv, const std::string& bnp, int O, int I, int R, const std::string& wkey, const std::string& bkey) {
+    const std::vector<float>& w = r->host.at(conv + ".weight");
+    const std::vector<float>&g = r->host.at(bnp + ".weight"), &be = r->host.at(bnp + ".bias"), &mu = r->host.at(bnp + ".running_mean"),
+                            &var = r->host.at(bnp + ".running_var");
+    const int sl = slab(r->dtype), Ip = (I + sl - 1) / sl * sl;
+    std::vector<float> wf((size_t)O * Ip * R * R, 0.f), bf(O);
+    for (int o = 0; o < O; ++o) {
+        const float scale = g[o] / sqrtf(var[o] + 1e-5f);
+        bf[o] = be[o] - mu[o] * scale;
+        for (int i = 0; i < I; ++i)
+            for (int k = 0; k < R * R; ++k) wf[((size_t)o * Ip + i) * R * R + k] = w[((size_t)o * I + i) * R * R + k] * scale;
+    }
+    void *tmp = nullptr, *dst = nullptr, *bp = nullptr;
+    ADVS_HIP(hipMalloc(&tmp, wf.size() * sizeof(float)));
+    hipError_t e = hipMemcpy(tmp, wf.data(), wf.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&dst, wf.size() * esz(r->dtype));
+    int rc = ADVS_OK;
+    if (e == hipSuccess) {
+        r->wbufs.push_back(dst);
+        rc = advs_pack_conv_weight((const float*)tmp, dst, O, Ip, R, R, r->dtype, r->stream);
+        if (rc == ADVS_OK) e = hipStreamSynchronize(r->stream);
+    }
+    (void)hipFree(tmp);
+    if (e != hipSuccess) ADVS_FAIL(ADVS_ERR_HIP, "resnet50 weights: %s", hipGetErrorString(e));
+    if (rc != ADVS_OK) return rc;
+    if ((rc = rn_dev_copy(r, bf.data(), bf.size(), &bp))) return rc;
+    r->W[wkey] = dst;
+    r->W[bkey] = bp;
+    return ADVS_OK;
+}
+
+int rn_pack(advs_resnet50* r) {
+    if (r->packed) return ADVS_OK;
+    for (auto& pr : r->params) ADVS_REQUIRE(r->host.count(pr.first), "advs_resnet50_plan: parameter %s was never set", pr.first.c_str());
+    int rc;
+    // the stem as a GEMM over im2col columns (advs_im2col_nchw): [64][3*7*7 -> whole slabs]
+    {
+        std::vector<float> w147 = r->host.at("conv1.weight");         // [64][3][7][7] = [64][147] as a 1x1 conv
+        r->host["__stem147.weight"] = w147;
+        for (const char* s : {".weight", ".bias", ".running_mean", ".running_var"}) r->host[std::string("__stembn") + s] = r->host.at(std::string("bn1") + s);
+        if ((rc = rn_fold_pack(r, "__stem147", "__stembn", 64, 147, 1, "stem.wg", "stem.b"))) return rc;
+        const int sl = slab(r->dtype);
+        r->stem_kp = (147 + sl - 1) / sl * sl;
+    }
+    for (auto& b : r->blocks) {
+        if ((rc = rn_fold_pack(r, b.p + ".conv1", b.p + ".bn1", b.width, b.cin, 1, b.p + ".w1", b.p + ".b1"))) return rc;
+        if ((rc = rn_fold_pack(r, b.p + ".conv2", b.p + ".bn2", b.width, b.width, 3, b.p + ".w2", b.p + ".b2"))) return rc;
+        if ((rc = rn_fold_pack(r, b.p + ".conv3", b.p + ".bn3", b.cout, b.width, 1, b.p + ".w3", b.p + ".b3"))) return rc;
+        if (b.ds && (rc = rn_fold_pack(r, b.p + ".downsample.0", b.p + ".downsample.1", b.cout, b.cin, 1, b.p + ".wd", b.p + ".bd"))) return rc;
+    }
+    void* q = nullptr;
+    if ((rc = rn_dev_copy(r, r->host.at("fc.weight").data(), r->host.at("fc.weight").size(), &q))) return rc;
+    r->W["fc.w"] = q;
+    if ((rc = rn_dev_copy(r, r->host.at("fc.bias").data(), r->host.at("fc.bias").size(), &q))) return rc;
+    r->W["fc.b"] = q;
+    r->packed = true;
+    return ADVS_OK;
+}
+
+void rn_drop_plan(advs_resnet50* r) {
+    r->fwd.destroy();
+    r->arena.destroy();
+    r->cargs.clear();
+    for (void* p : {(void*)r->x, (void*)r->logits, (void*)r->hwc, (void*)r->rs1, (void*)r->rs2, (void*)r->bounds, (void*)r->coefs})
+        if (p) (void)hipFree(p);
+    r->x = r->logits = nullptr; r->hwc = r->rs1 = r->rs2 = nullptr; r->bounds = r->coefs = nullptr;
+    r->B = r->S = r->src = 0;
+}
+
+// _ResNetEngine.__init__ (this package's victims.py)
+int rn_emit(advs_resnet50* r) {
+    int rc = ADVS_OK;
+    const int B = r->B, S = r->S, dt = r->dtype;
+    auto alloc = [&](size_t bytes) { void* p = nullptr; if (rc == ADVS_OK) rc = r->arena.alloc(bytes, &p); return p; };
+    auto buf = [&](int H, int W, int C) { Act a; a.p = alloc((size_t)B * H * W * C * esz(dt)); a.B = B; a.H = H; a.W = W; a.C = C; return a; };
+    auto conv = [&](const Act& x, const std::string& wk, const std::string& bk, int cout, int ksize, int stride, int pad, int act, const Act* res) {
+        const int Ho = (x.H + 2 * pad - ksize) / stride + 1, Wo = (x.W + 2 * pad - ksize) / stride + 1;
+        Act y = buf(Ho, Wo, cout);
+        r->cargs.emplace_back();
+        advs_conv_args& a = r->cargs.back();
+        memset(&a, 0, sizeof(a));
+        a.x1 = x.p; a.w = r->W.at(wk); a.bias = (const float*)r->W.at(bk); a.residual = res ? res->p : nullptr; a.y = y.p;
+        a.b = B; a.h = x.H; a.w_ = x.W; a.c1 = x.C; a.cout = cout; a.ksize = ksize; a.stride = stride; a.pad = pad; a.act = act; a.dtype = dt;
+        const advs_conv_args* ap = &a;
+        r->fwd.ops.push_back([ap](hipStream_t s) { return advs_conv2d(ap, s); });
+        return y;
+    };
+    const int ho = (S + 6 - 7) / 2 + 1, kp = r->stem_kp;
+    Act cols = buf(ho, ho, kp);
+    {
+        const float* xp = r->x;
+        void* cp = cols.p;
+        r->fwd.ops.push_back([=](hipStream_t s) { return advs_im2col_nchw(xp, cp, B, 3, S, S, 7, 2, 3, kp, dt, s); });
+    }
+    Act h = conv(cols, "stem.wg", "stem.b", 64, 1, 1, 0, ADVS_ACT_RELU, nullptr);
+    r->arena.release(cols.p);
+    const int hp = (ho + 2 - 3) / 2 + 1;
+    Act pooled = buf(hp, hp, 64);
+    {
+        const void* hpn = h.p;
+        void* pp = pooled.p;
+        r->fwd.ops.push_back([=](hipStream_t s) { return advs_maxpool3x3s2(hpn, pp, B, ho, ho, 64, dt, s); });
+    }
+    r->arena.release(h.p);
+    h = pooled;
+    for (auto& b : r->blocks) {
+        Act y1 = conv(h, b.p + ".w1", b.p + ".b1", b.width, 1, 1, 0, ADVS_ACT_RELU, nullptr);
+        Act y2 = conv(y1, b.p + ".w2", b.p + ".b2", b.width, 3, b.stride, 1, ADVS_ACT_RELU, nullptr);
+        r->arena.release(y1.p);
+        Act idn = b.ds ? conv(h, b.p + ".wd", b.p + ".bd", b.cout, 1, b.stride, 0, ADVS_ACT_NONE, nullptr) : h;
+        Act y3 = conv(y2, b.p + ".w3", b.p + ".b3", b.cout, 1, 1, 0, ADVS_ACT_RELU, &idn);
+        r->arena.release(y2.p);
+        if (b.ds) r->arena.release(idn.p);
+        r->arena.release(h.p);
+        h = y3;
+    }
+    float* avg = (float*)alloc((size_t)B * h.C * sizeof(float));
+    {
+        const void* hpn = h.p;
+        const int hw = h.H * h.W, C = h.C, nc = r->num_classes;
+        const float *fw = (const float*)r->W.at("fc.w"), *fb = (const float*)r->W.at("fc.b");
+        float* lg = r->logits;
+        r->fwd.ops.push_back([=](hipStream_t s) { return advs_global_avgpool(hpn, avg, B, hw, C, dt, s); });
+        r->fwd.ops.push_back([=](hipStream_t s) { return advs_linear_f32(avg, fw, fb, lg, B, C, nc, ADVS_ACT_NONE, ADVS_ACT_NONE, s); });
+    }
+    return rc;
+}
+
+}  // namespace
+
+extern "C" int advs_resnet50_create(int num_classes, int dtype, advs_resnet50** out) {
+    ADVS_REQUIRE(out && num_classes > 0, "advs_resnet50_create: bad arguments");
+    ADVS_REQUIRE(dtype == ADVS_F32 || dtype == ADVS_BF16 || dtype == ADVS_F16, "advs_resnet50_create: unknown dtype %d", dtype);
+    advs_resnet50* r = new advs_resnet50();
+    r->num_classes = num_classes;
+    r->dtype = dtype;
+    rn_params(r);
+    *out = r;
+    return ADVS_OK;
+}
+extern "C" int advs_resnet50_param_count(const advs_resnet50* r) { return r ? (int)r->params.size() : 0; }
+extern "C" int advs_resnet50_param_name(const advs_resnet50* r, int i, char* name, int name_len, long long* numel) {
+    ADVS_REQUIRE(r && i >= 0 && i < (int)r->params.size() && name && name_len > 0, "advs_resnet50_param_name: bad index");
+    ADVS_REQUIRE((int)r->params[i].first.size() < name_len, "advs_resnet50_param_name: %d bytes are too few for %s", name_len, r->params[i].first.c_str());
+    snprintf(name, (size_t)name_len, "%s", r->params[i].first.c_str());
+    if (numel) *numel = r->params[i].second;
+    return ADVS_OK;
+}
+extern "C" int advs_resnet50_set_param(advs_resnet50* r, const char* name, const float* host_data, long long numel) {
+    ADVS_REQUIRE(r && name && host_data, "advs_resnet50_set_param: null pointer");
+    long long want = -1;
+    for (auto& pr : r->params)
+        if (pr.first == name) want = pr.second;
+    ADVS_REQUIRE(want >= 0, "advs_resnet50_set_param: %s is not a parameter of this network (BatchNorm's num_batches_tracked is not one)", name);
+    ADVS_REQUIRE(numel == want, "advs_resnet50_set_param: %s has %lld elements, got %lld", name, want, numel);
+    r->host[name].assign(host_data, host_data + numel);
+    if (r->packed) {
+        rn_drop_plan(r);
+        for (void* p : r->wbufs) (void)hipFree(p);
+        r->wbufs.clear(); r->W.clear(); r->packed = false;
+    }
+    return ADVS_OK;
+}
+
+// batch images of size x size into the victim; src_size > 0 also prepares advs_resnet50_eval_u8's chain for src_size x src_size uint8 images
+extern "C" int advs_resnet50_plan(advs_resnet50* r, int batch, int size, int src_size, void* stream) {
+    ADVS_REQUIRE(r && batch > 0 && size >= 32 && src_size >= 0 && stream, "advs_resnet50_plan: bad arguments (an explicit stream is needed)");
+    int rc = advs_init();
+    if (rc != ADVS_OK) return rc;
+    if (r->B) rn_drop_plan(r);
+    r->stream = (hipStream_t)stream;
+    if ((rc = rn_pack(r))) return rc;
+    r->B = batch; r->S = size; r->src = src_size;
+    ADVS_HIP(hipMalloc((void**)&r->x, (size_t)batch * 3 * size * size * sizeof(float)));
+    ADVS_HIP(hipMalloc((void**)&r->logits, (size_t)batch * r->num_classes * sizeof(float)));
+    ADVS_HIP(hipMemset(r->x, 0, (size_t)batch * 3 * size * size * sizeof(float)));
+    if (src_size > 0) {
+        ADVS_HIP(hipMalloc((void**)&r->hwc, (size_t)batch * src_size * src_size * 3));
+        if (src_size != size) {
+            ADVS_HIP(hipMalloc((void**)&r->rs1, (size_t)batch * src_size * size * 3));
+            ADVS_HIP(hipMalloc((void**)&r->rs2, (size_t)batch * size * size * 3));
+            int ks = 0;
+            if ((rc = advs_resize_tables(src_size, size, nullptr, nullptr, &ks))) { rn_drop_plan(r); return rc; }
+            std::vector<int> bd(2 * size), cf((size_t)size * ks);
+            if ((rc = advs_resize_tables(src_size, size, bd.data(), cf.data(), &ks))) { rn_drop_plan(r); return rc; }
+            r->ksize = ks;
+            ADVS_HIP(hipMalloc((void**)&r->bounds, bd.size() * sizeof(int)));
+            ADVS_HIP(hipMalloc((void**)&r->coefs, cf.size() * sizeof(int)));
+            ADVS_HIP(hipMemcpy(r->bounds, bd.data(), bd.size() * sizeof(int), hipMemcpyHostToDevice));
+            ADVS_HIP(hipMemcpy(r->coefs, cf.data(), cf.size() * sizeof(int), hipMemcpyHostToDevice));
+        }
+    }
+    if ((rc = rn_emit(r))) { rn_drop_plan(r); return rc; }
+    if ((rc = r->fwd.run_eager(r->stream))) { rn_drop_plan(r); return rc; }
+    ADVS_HIP(hipStreamSynchronize(r->stream));
+    if ((rc = r->fwd.capture(r->stream))) { rn_drop_plan(r); return rc; }
+    return ADVS_OK;
+}
+
+// logits = model(x): x [B][3][S][S] f32, logits [B][num_classes] f32, device pointers, stream-ordered (ASR_fast.py:113-115)
+extern "C" int advs_resnet50_forward(advs_resnet50* r, const float* x_nchw, float* logits) {
+    ADVS_REQUIRE(r && x_nchw && logits, "advs_resnet50_forward: null pointer");
+    ADVS_REQUIRE(r->B > 0, "advs_resnet50_forward: no plan (advs_resnet50_plan first)");
+    ADVS_HIP(hipMemcpyAsync(r->x, x_nchw, (size_t)r->B * 3 * r->S * r->S * sizeof(float), hipMemcpyDeviceToDevice, r->stream));
+    const int rc = r->fwd.run(r->stream);
+    if (rc != ADVS_OK) return rc;
+    ADVS_HIP(hipMemcpyAsync(logits, r->logits, (size_t)r->B * r->num_classes * sizeof(float), hipMemcpyDeviceToDevice, r->stream));
+    return ADVS_OK;
+}
+
+// asr.evaluate_batch (ASR_fast.py:90-97, 113-117): uint8 [B][3][src][src] sampler output -> HWC -> Resize((S, S)) (Pillow BILINEAR, horizontal
+// pass first) -> ToTensor -> victim -> argmax.  pred: int32 [B] on the device.  Stream-ordered.
+extern "C" int advs_resnet50_eval_u8(advs_resnet50* r, const uint8_t* images_nchw, int* pred) {
+    ADVS_REQUIRE(r && images_nchw && pred, "advs_resnet50_eval_u8: null pointer");
+    ADVS_REQUIRE(r->B > 0 && r->src > 0, "advs_resnet50_eval_u8: needs a plan made with src_size > 0");
+    void* s = r->stream;
+    const int B = r->B, S = r->S, src = r->src;
+    int rc;
+    if ((rc = advs_u8_nchw_to_hwc(images_nchw, r->hwc, B, 3, src, src, s))) return rc;
+    const unsigned char* img = r->hwc;
+    if (src != S) {
+        if ((rc = advs_resample_u8(r->hwc, r->rs1, r->bounds, r->coefs, r->ksize, B, src, src, src, S, 3, 1, s))) return rc;
+        if ((rc = advs_resample_u8(r->rs1, r->rs2, r->bounds, r->coefs, r->ksize, B, src, S, S, S, 3, 0, s))) return rc;
+        img = r->rs2;
+    }
+    if ((rc = advs_u8hwc_to_f32nchw(img, r->x, B, S, S, 3, nullptr, nullptr, s))) return rc;
+    if ((rc = r->fwd.run(r->stream))) return rc;
+    return advs_argmax_rows(r->logits, pred, B, r->num_classes, s);
+}
+
+extern "C" void advs_resnet50_destroy(advs_resnet50* r) {
+    if (!r) return;
+    rn_drop_plan(r);
+    for (void* p : r->wbufs) (void)hipFree(p);
+    delete r;
+}

@@ -98,3 +98,69 @@ def ddim_tables(timesteps=1000, ddim_timesteps=50, beta_schedule="cosine", metho
     tseq = np.zeros((n.value,), np.int64)
     check(lib.advs_ddim_tables(*args, coef.ctypes.data, tseq.ctypes.data, C.byref(n)), "advs_ddim_tables")
     return coef, tseq
+
+
+class CResNet50:
+    """``advs_resnet50`` (the victim of ASR_fast.py:16-20) behind the C handle: ``forward`` and the uint8 evaluation chain."""
+
+    def __init__(self, num_classes=37, compute_dtype="fp32"):
+        _lib.init_device()
+        self.lib = _lib.load()
+        self.h = C.c_void_p()
+        self.num_classes = num_classes
+        check(self.lib.advs_resnet50_create(num_classes, dtype_code(compute_dtype), C.byref(self.h)), "advs_resnet50_create")
+        self.stream, self.batch, self.size = None, 0, 0
+
+    def param_names(self):
+        out, buf, n = [], C.create_string_buffer(256), C.c_longlong()
+        for i in range(self.lib.advs_resnet50_param_count(self.h)):
+            check(self.lib.advs_resnet50_param_name(self.h, i, buf, 256, C.byref(n)), "advs_resnet50_param_name")
+            out.append((buf.value.decode(), n.value))
+        return out
+
+    def load_state_dict(self, sd):
+        for name, _ in self.param_names():
+            a = np.ascontiguousarray(torch.as_tensor(sd[name]).detach().float().cpu().numpy().reshape(-1))
+            check(self.lib.advs_resnet50_set_param(self.h, name.encode(), a.ctypes.data, a.size), f"advs_resnet50_set_param({name})")
+
+    def plan(self, batch, size=224, src_size=0, stream=None):
+        self.stream = stream if stream is not None else torch.cuda.Stream()
+        check(self.lib.advs_resnet50_plan(self.h, batch, size, src_size, self.stream.cuda_stream), "advs_resnet50_plan")
+        self.batch, self.size = batch, size
+
+    def forward(self, x):
+        x = x.contiguous().float()
+        out = torch.empty((self.batch, self.num_classes), dtype=torch.float32, device=x.device)
+        self.stream.wait_stream(torch.cuda.current_stream(x.device))
+        check(self.lib.advs_resnet50_forward(self.h, x.data_ptr(), out.data_ptr()), "advs_resnet50_forward")
+        self.stream.synchronize()
+        return out
+
+    def eval_u8(self, images_u8_nchw):
+        x = images_u8_nchw.contiguous()
+        pred = torch.empty((self.batch,), dtype=torch.int32, device=x.device)
+        self.stream.wait_stream(torch.cuda.current_stream(x.device))
+        check(self.lib.advs_resnet50_eval_u8(self.h, x.data_ptr(), pred.data_ptr()), "advs_resnet50_eval_u8")
+        self.stream.synchronize()
+        return pred
+
+    def close(self):
+        if self.h:
+            self.lib.advs_resnet50_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def resize_tables(in_size, out_size):
+    """advs_resize_tables: (bounds int32 [out, 2], coefs int32 [out, ksize], ksize)."""
+    lib = _lib.load()
+    ks = C.c_int()
+    check(lib.advs_resize_tables(in_size, out_size, None, None, C.byref(ks)), "advs_resize_tables")
+    b, k = np.zeros((out_size, 2), np.int32), np.zeros((out_size, ks.value), np.int32)
+    check(lib.advs_resize_tables(in_size, out_size, b.ctypes.data, k.ctypes.data, C.byref(ks)), "advs_resize_tables")
+    return b, k, ks.value

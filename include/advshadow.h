@@ -311,7 +311,8 @@ int advs_unpatchify_padded(const void* dcols, float* dx_nchw, int b, int cin, in
  * Closed form of apply_shadow (tools/train_shadow.py:242-256,262-266; ddim2/test.py:830-871; with
  * ntaps = 1, taps = {1}: ddim2/diff_model2.py:615-654): circular mask at centers[b] = (cx, cy) with
  * radii[b], blurred by the separable `taps` (cv2.GaussianBlur(k, sigma 0), BORDER_REFLECT_101),
- * times feature_mask; img/out NCHW f32 [b][c][h][w], feature_mask [b][mask_channels][h][w].     */
+ * times feature_mask; img/out NCHW f32 [b][c][h][w], feature_mask [b][mask_channels][h][w].
+ * `taps` is a HOST array of ntaps (odd, <= 7) floats: it travels in the launch arguments.        */
 int advs_apply_shadow(const float* img, const float* feature_mask, const float* centers, const float* radii,
                       float* out, int b, int c, int h, int w, int mask_channels, float intensity,
                       const float* taps, int ntaps, void* stream);
@@ -486,6 +487,26 @@ int advs_ddim_tables(int cosine_schedule, int timesteps, int ddim_timesteps, int
                      int64_t* tseq_out, int* nsteps_out);
 int advs_ddim_run(advs_unet* u, float* x, const float* coef, const int64_t* tseq, int nsteps, int clip_denoised);
 void advs_unet_destroy(advs_unet* u);
+
+/* The victim side of the attack loop for the same kind of host (csrc/unet_handle.hip, second half): ResNet-50 in the timm / torchvision
+ * layout (ASR_fast.py:16-20, ddim2/diff_model2.py:19-44; state_dict keys without BatchNorm's num_batches_tracked; BatchNorm is folded
+ * into the convs in f32) and the evaluation chain in front of it.
+ *   advs_resize_tables     Pillow's precompute_coeffs + normalize_coeffs_8bpc for BILINEAR (what transforms.Resize does to a PIL image,
+ *                          ASR_fast.py:94, PSNR_SSIM_fast.py:10-13): the bounds / coefs advs_resample_u8 takes.  NULL tables = size query.
+ *   advs_resnet50_plan     batch images of size x size; src_size > 0 also prepares advs_resnet50_eval_u8 for src_size x src_size uint8 input.
+ *   advs_resnet50_forward  logits = model(x) (ASR_fast.py:113-115); device pointers, stream-ordered.
+ *   advs_resnet50_eval_u8  asr.evaluate_batch: uint8 [b][3][src][src] sampler output -> HWC -> Resize((size, size)) -> ToTensor -> victim ->
+ *                          argmax (ASR_fast.py:90-97, 113-117); pred int32 [b] on the device.                                        */
+typedef struct advs_resnet50 advs_resnet50;
+int advs_resize_tables(int in_size, int out_size, int* bounds, int* coefs, int* ksize_out);
+int advs_resnet50_create(int num_classes, int dtype, advs_resnet50** out);
+int advs_resnet50_param_count(const advs_resnet50* r);
+int advs_resnet50_param_name(const advs_resnet50* r, int i, char* name, int name_len, long long* numel);
+int advs_resnet50_set_param(advs_resnet50* r, const char* name, const float* host_data, long long numel);
+int advs_resnet50_plan(advs_resnet50* r, int batch, int size, int src_size, void* stream);
+int advs_resnet50_forward(advs_resnet50* r, const float* x_nchw, float* logits);
+int advs_resnet50_eval_u8(advs_resnet50* r, const uint8_t* images_nchw, int* pred);
+void advs_resnet50_destroy(advs_resnet50* r);
 
 /* ---- stream capture (hipGraph) -------------------------------------------------------- */
 int advs_graph_begin(void* stream);

@@ -204,3 +204,30 @@ def test_header_is_valid_c():
     r = subprocess.run(["gcc", "-std=c11", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include",
                         "-fsyntax-only", os.path.join(ROOT, "examples", "c_host_ddim.c")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_handle_resnet50_registry_and_resize_tables():
+    """Host-only parts of the victim handle: the parameter names are the ResNet-50 state_dict (without num_batches_tracked), and
+    advs_resize_tables equals imageops.bilinear_coeffs (Pillow's precompute_coeffs / normalize_coeffs_8bpc) entry for entry."""
+    import ctypes as C
+    from advshadow_amd.imageops import bilinear_coeffs
+    from advshadow_amd.victims import ResNet50
+    lib = _lib.load()
+    h = C.c_void_p()
+    assert lib.advs_resnet50_create(37, 1, C.byref(h)) == 0
+    buf, n = C.create_string_buffer(256), C.c_longlong()
+    got = []
+    for i in range(lib.advs_resnet50_param_count(h)):
+        assert lib.advs_resnet50_param_name(h, i, buf, 256, C.byref(n)) == 0
+        got.append((buf.value.decode(), n.value))
+    sd = ResNet50(num_classes=37).state_dict()
+    assert got == [(k, v.numel()) for k, v in sd.items() if not k.endswith("num_batches_tracked")]
+    assert lib.advs_resnet50_set_param(h, b"bn1.num_batches_tracked", None, 0) != 0
+    lib.advs_resnet50_destroy(h)
+    for a, b in ((256, 224), (256, 64), (224, 224), (64, 224), (500, 224), (37, 64), (1000, 3)):
+        b1, k1, ks1 = bilinear_coeffs(a, b)
+        ks = C.c_int()
+        assert lib.advs_resize_tables(a, b, None, None, C.byref(ks)) == 0 and ks.value == ks1
+        b2, k2 = np.zeros((b, 2), np.int32), np.zeros((b, ks.value), np.int32)
+        assert lib.advs_resize_tables(a, b, b2.ctypes.data, k2.ctypes.data, C.byref(ks)) == 0
+        assert np.array_equal(b1, b2) and np.array_equal(k1, k2), (a, b)
