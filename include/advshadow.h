@@ -317,7 +317,7 @@ int advs_apply_shadow(const float* img, const float* feature_mask, const float* 
                       float* out, int b, int c, int h, int w, int mask_channels, float intensity,
                       const float* taps, int ntaps, void* stream);
 /* The same composite stopped half way, for the gradient attack of train_shadow.py:250-260: the shadowed image (NOT
- * clamped) and the combined mask cm = blur(shadow mask) * feature mask, both [b][c][h][w] f32.                     */
+ * clamped) and the combined mask cm = blur(shadow mask) * feature mask, both [b][c][h][w] f32.  `taps`: HOST array, as above. */
 int advs_apply_shadow_parts(const float* img, const float* feature_mask, const float* centers, const float* radii,
                             float* shadowed, float* cmask, int b, int c, int h, int w, int mask_channels,
                             float intensity, const float* taps, int ntaps, void* stream);
